@@ -1,0 +1,163 @@
+"""Generate ``tests/golden/*.npz`` by EXECUTING THE UNMODIFIED REFERENCE (read-only import of
+``/root/reference/daam``) on fake SD-v1.5 / SDXL topologies.  TEST INFRASTRUCTURE.
+
+Runs only in the build container (``/root/reference`` does not exist on the GPU box); the
+resulting fixtures are committed and are what ``tests/`` compare against at run time.
+
+    python -m oracle.make_golden            # regenerate every case
+    python -m oracle.make_golden sd15_f32   # one case
+
+What is the reference and what is scaffolding:
+  * reference code executed as-is: ``UNetCrossAttentionLocator.locate`` (hook.py:95-127),
+    ``DiffusionHeatMapHooker`` / ``UNetCrossAttentionHooker.__call__`` / ``_unravel_attn``
+    (trace.py), ``RawHeatMapCollection.update`` (heatmap.py:153-156),
+    ``compute_global_heat_map`` (trace.py:83-132), ``GlobalHeatMap.compute_word_heat_map``
+    (heatmap.py:121-123), ``WordHeatMap.expand_as`` (heatmap.py:77-93).
+  * scaffolding (``oracle/fake_diffusers.py``): the diffusers ``Attention`` restatement, the
+    UNet block structure, the synthetic hidden states.  Projections are identity so the
+    hidden states ARE Q / K and the fixtures pin exact input bits.
+  * fp16 cases: the per-step path runs literally in fp16 on CPU.  ``compute_global_heat_map``
+    on a GPU runs under ``autocast(float32)``, which up-casts the bicubic input to fp32
+    (SURVEY.md section 5); with no GPU here autocast is disabled, so for fp16 cases the
+    accumulated maps are cast to fp32 before the reference's ``compute_global_heat_map`` is
+    called -- the only deviation from "unmodified", stated in the fixture meta.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+from oracle import fake_diffusers as fd
+
+OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+LONG_PROMPT = ' '.join(f'w{i}' for i in range(75))     # 75 tokens -> 77 rows
+
+CASES = {
+    # config C1 flavour: SD-v1.5 topology, fp32, CFG batch 2, 5 steps, prompt 'a dog'
+    'sd15_f32': dict(kind='sd15', dtype='float32', batch=2, steps=5, prompt='a dog', seed=11,
+                     unet=dict(dim_head=8)),
+    # same topology, literal fp16 pipeline, more steps so fp16 running sums round
+    'sd15_f16': dict(kind='sd15', dtype='float16', batch=2, steps=12, prompt='a dog', seed=12,
+                     unet=dict(dim_head=16)),
+    # SDXL topology (60 layers -> capped transformer blocks, fewer heads), factors {1,2}
+    'sdxl_f32': dict(kind='sdxl', dtype='float32', batch=2, steps=2, prompt='a photo of a monkey', seed=13,
+                     unet=dict(dim_head=8, heads_scale=0.2, tblocks_cap=2)),
+    'sdxl_f16': dict(kind='sdxl', dtype='float16', batch=2, steps=6, prompt=LONG_PROMPT, seed=14,
+                     unet=dict(dim_head=16, heads_scale=0.2, tblocks_cap=1),
+                     variants=['default', 'normalize']),
+    # SDXL asked for 2048x2048: config.sample_size stays 128, latent 256 -> factors {0,1},
+    # bicubic x0.5 (down-sample, no antialias) and x1
+    'sdxl2048_f32': dict(kind='sdxl', dtype='float32', batch=2, steps=1, prompt='a dog', seed=15,
+                         unet=dict(dim_head=8, heads_scale=0.1, tblocks_cap=1, latent_size=256)),
+    # reference quirks: no CFG (batch 1 keeps heads H/2..H-1, trace.py:240) and
+    # num_images_per_prompt=2 under CFG (batch 4 -> "heads" = 2H)
+    'sd15_nocfg_f32': dict(kind='sd15', dtype='float32', batch=1, steps=2, prompt='a dog', seed=16,
+                           unet=dict(dim_head=8)),
+    'sd15_b4_f32': dict(kind='sd15', dtype='float32', batch=4, steps=2, prompt='a dog', seed=17,
+                        unet=dict(dim_head=8, heads_scale=0.25)),
+}
+
+SAMPLE_TOKENS = [0, 1, 2, 76]
+
+
+def input_checksums(pipe, steps):
+    """Cheap fingerprint of the synthetic inputs so a test can prove it regenerated the
+    same bits."""
+    s = []
+    order = pipe.unet.execution_order()
+    for i, spec in enumerate(order):
+        x = pipe.hidden_states(i, spec, steps - 1).double()
+        c = pipe.context(i, spec).double()
+        s.append([float(x.sum()), float((x * x).sum()), float(c.sum()), float((c * c).sum())])
+    return np.asarray(s, dtype=np.float64)
+
+
+def run_case(name, spec, daam):
+    dtype = getattr(torch, spec['dtype'])
+    pipe = fd.make_pipe(spec['kind'], dtype=dtype, batch=spec['batch'], seed=spec['seed'],
+                        mini=True, identity_proj=True, **spec['unet'])
+    out = {}
+    with daam.trace(pipe) as tc:
+        pipe(spec['prompt'], num_inference_steps=spec['steps'], callback=tc.time_callback)
+        items = list(tc.all_heat_maps)
+        keys = np.asarray([k for k, _ in items], dtype=np.int32)
+        out['keys'] = keys
+        out['key_sum'] = np.asarray([float(v.double().sum()) for _, v in items])
+        out['key_sumsq'] = np.asarray([float((v.double() ** 2).sum()) for _, v in items])
+        out['raw_dtype'] = np.asarray(str(items[0][1].dtype))
+        # one sampled raw map per distinct resolution (first + last key of that factor)
+        sample_ids = []
+        for f in sorted(set(keys[:, 0].tolist())):
+            ids = np.nonzero(keys[:, 0] == f)[0]
+            sample_ids += [int(ids[0]), int(ids[-1])]
+        out['raw_sample_ids'] = np.asarray(sample_ids, dtype=np.int32)
+        for sid in sample_ids:
+            out[f'raw_{sid}'] = items[sid][1][SAMPLE_TOKENS].float().numpy()
+        if dtype == torch.float16:
+            # emulate CUDA autocast(float32): upsample_bicubic2d is on the FP32 policy list
+            hm = tc.all_heat_maps.ids_to_heatmaps
+            for k in list(hm.keys()):
+                hm[k] = hm[k].float()
+        layers = sorted(set(keys[:, 1].tolist()))
+        heads = sorted(set(keys[:, 2].tolist()))
+        factors = sorted(set(keys[:, 0].tolist()))
+        variants = {
+            'default': {},
+            'normalize': dict(normalize=True),
+            'factor_hi': dict(factors=[factors[-1]]),
+            'factor_lo': dict(factors=[factors[0]]),
+            'head': dict(head_idx=heads[len(heads) // 2]),
+            'layer': dict(layer_idx=layers[len(layers) // 2]),
+            'layer_head': dict(layer_idx=layers[-1], head_idx=heads[0], normalize=True),
+        }
+        if 'variants' in spec:
+            variants = {vn: variants[vn] for vn in spec['variants']}
+        for vn, kw in variants.items():
+            ghm = tc.compute_global_heat_map(**kw)
+            out[f'global_{vn}'] = ghm.heat_maps.float().numpy()
+        out['variants'] = np.asarray(json.dumps(variants))
+        ghm = tc.compute_global_heat_map()
+        # next-row f1: word heat map + expand_as (heatmap.py:77-93, 121-123)
+        word = spec['prompt'].split()[-1]
+        whm = ghm.compute_word_heat_map(word)
+        out['word'] = np.asarray(word)
+        out['word_map'] = whm.heatmap.float().numpy()
+
+        class _Img:
+            size = (128, 128)
+        out['word_expand_128'] = whm.expand_as(_Img()).numpy()
+        out['word_expand_128_abs'] = whm.expand_as(_Img(), absolute=True).numpy()
+        out['layer_names'] = np.asarray(json.dumps(tc.layer_names))
+        out['last_prompt'] = np.asarray(tc.last_prompt)
+        out['last_image'] = np.asarray(str(tc.last_image))
+        out['time_idx'] = np.asarray(tc.time_idx)
+    out['input_checksums'] = input_checksums(pipe, spec['steps'])
+    meta = dict(spec)
+    meta['reference'] = 'castorini/daam v0.2.0, executed unmodified via oracle/fake_diffusers.py'
+    meta['fp16_note'] = 'fp16 accumulators cast to fp32 before compute_global_heat_map (CUDA autocast emulation)'
+    meta['torch'] = torch.__version__
+    out['meta'] = np.asarray(json.dumps(meta))
+    path = os.path.join(OUT_DIR, f'{name}.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: {len(keys)} keys, factors {factors}, global {out["global_default"].shape}, '
+          f'{os.path.getsize(path) / 1e6:.2f} MB')
+
+
+def main(argv):
+    warnings.filterwarnings('ignore')
+    torch.set_num_threads(os.cpu_count() or 1)
+    daam, _ = fd.import_reference()
+    os.makedirs(OUT_DIR, exist_ok=True)
+    names = argv or list(CASES)
+    for n in names:
+        run_case(n, CASES[n], daam)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])

@@ -1,0 +1,77 @@
+"""The numpy oracle (oracle/heatmap_oracle.py) against the golden vectors produced by
+executing the unmodified reference (oracle/make_golden.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden_pipe
+from oracle import heatmap_oracle as ho
+from oracle.make_golden import SAMPLE_TOKENS, input_checksums
+
+
+def _tol(meta):
+    # fp32: differences are summation-order only.  fp16: identical rounding points; a
+    # straddled fp16 rounding in a logit moves one probability by 1 ulp (<= 4.9e-4) once.
+    return 2e-6 if meta['dtype'] == 'float32' else 2e-4
+
+
+def test_oracle_matches_reference(golden_case):
+    name, z, meta = golden_case
+    pipe = golden_pipe(meta)
+    np.testing.assert_allclose(input_checksums(pipe, meta['steps']), z['input_checksums'], rtol=0, atol=0)
+    import torch
+    dt = getattr(torch, meta['dtype'])
+    raw = ho.replay_generation(pipe, meta['steps'], dt)
+    keys = np.asarray([k for k, _ in raw], dtype=np.int32)
+    np.testing.assert_array_equal(keys, z['keys'])          # same keys, same insertion order
+    sums = np.asarray([float(v.astype(np.float64).sum()) for _, v in raw])
+    np.testing.assert_allclose(sums, z['key_sum'], rtol=1e-4 if meta['dtype'] == 'float16' else 1e-5)
+    items = list(raw)
+    for sid in z['raw_sample_ids']:
+        got = items[int(sid)][1][SAMPLE_TOKENS].astype(np.float32)
+        want = z[f'raw_{int(sid)}']
+        # fp16 running sums: one flipped rounding = 1 ulp of the sum (SOS sums reach ~steps)
+        tol = _tol(meta) if meta['dtype'] == 'float32' else 2.0 ** -10 * max(1.0, float(want.max()))
+        np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+    lat = ho.latent_hw_for(pipe.unet.config.sample_size, pipe.vae_scale_factor)
+    n_rows = len(pipe.tokenizer.tokenize(meta['prompt'])) + 2
+    variants = json.loads(str(z['variants']))
+    for vn, kw in variants.items():
+        got = ho.global_heat_map(raw, lat, n_rows=n_rows, **kw)
+        want = z[f'global_{vn}']
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=_tol(meta) * max(1.0, float(np.abs(want).max())),
+                                   err_msg=f'{name}:{vn}')
+
+
+def test_oracle_word_heat_map(golden_case):
+    name, z, meta = golden_case
+    pipe = golden_pipe(meta)
+    gm = z['global_default']
+    word = str(z['word'])
+    toks = pipe.tokenizer.tokenize(meta['prompt'].lower())
+    idxs, _ = ho.token_merge_indices(toks, pipe.tokenizer.tokenize(word.lower()), word)
+    wm = ho.word_heat_map(gm, idxs)
+    np.testing.assert_allclose(wm, z['word_map'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ho.expand_as(wm, 128), z['word_expand_128'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ho.expand_as(wm, 128, absolute=True), z['word_expand_128_abs'], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize('i,o', [(32, 64), (16, 64), (64, 64), (128, 64), (64, 128), (24, 96), (64, 512)])
+def test_bicubic_matches_torch(i, o):
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(i * 1000 + o)
+    x = rng.standard_normal((3, i, i)).astype(np.float32)
+    want = F.interpolate(torch.from_numpy(x)[:, None], size=(o, o), mode='bicubic')[:, 0].numpy()
+    got = ho.bicubic_resize(x, o)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-6)
+
+
+def test_no_maps_errors():
+    raw = ho.RawMaps()
+    with pytest.raises(RuntimeError, match='Did you forget'):
+        ho.global_heat_map(raw, 4096)
+    with pytest.raises(RuntimeError, match='given parameters'):
+        ho.global_heat_map(raw, 4096, head_idx=3)
