@@ -1,0 +1,326 @@
+#!/usr/bin/env python
+"""Benchmark of the DAAM heat-map extraction path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One bench "step" = the extraction work of ONE generation (one prompt/seed) of the workload:
+reset of the running sums, ``denoise_steps`` x (all hooked cross-attention layers) taps from
+synthetic fp16 Q / K already resident in HBM, the final flush, and one
+``compute_global_heat_map`` (bicubic + clamp + mean over all keys) -> one ``[77, 64, 64]``
+global heat map.  Default workload = BASELINE.json configs[2]: SDXL-base-1.0 topology at
+1024x1024 (60 hooked layers, 1100 (layer, head) keys), 50 denoising steps, 77 tokens, CFG batch 2.
+Every tap goes through the per-layer C-ABI call the attention processor makes (``daam_tap_qk_enqueue``
+/ ``daam_tap_flush``), so the reported rate includes the host cost of that path.
+
+Multi-GPU: generations are independent (the reference is single-prompt by construction,
+daam/trace.py:172-173): rank r runs its own K generations; the only exchange is one RCCL
+all_gather of the final maps, inside the timed region.  ``scaling`` = weak.
+
+The one JSON line also carries ``roofline`` (tap kernel: algorithmic bytes / HIP-event time of
+back-to-back launches) and ``cpu_baseline`` (the torch port of the reference's hook path,
+oracle/torch_hooks.py, timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
+
+WORKLOADS = {
+    'sdxl1024': dict(kind='sdxl', latent=128, label='SDXL-base-1.0 topology 1024x1024, 60 layers / 1100 keys'),
+    'sdxl2048': dict(kind='sdxl', latent=256, label='SDXL-base-1.0 topology 2048x2048, 60 layers / 1100 keys'),
+    'sd15': dict(kind='sd15', latent=64, label='SD-v1.5 topology 512x512, 15 layers / 120 keys'),
+}
+
+
+def topology(kind, latent):
+    """(layer_idx, heads, side, head_dim) of the hooked layers in UNet execution order
+    (down blocks, then up blocks); layer_idx = locator position."""
+    if kind == 'sdxl':
+        a, b = latent // 2, latent // 4
+        loc = ([(i, 20, b, 64) for i in range(0, 30)] + [(i, 10, a, 64) for i in range(30, 40)] +
+               [(i, 20, b, 64) for i in range(40, 60)])
+        return loc[36:] + loc[:36]
+    s = [latent // 4, latent // 2, latent]
+    up = [(i, 8, s[i // 3], [160, 80, 40][i // 3]) for i in range(9)]
+    down = [(9 + i, 8, [latent, latent // 2, latent // 4][i // 2], [40, 80, 160][i // 2]) for i in range(6)]
+    return down + up
+
+
+def make_inputs(layers, pool, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    sets = []
+    for _ in range(pool):
+        cur = []
+        for (_, heads, side, d) in layers:
+            q = torch.randn(2, side * side, heads * d, generator=g, device=device, dtype=torch.float16)
+            k = torch.randn(2, 77, heads * d, generator=g, device=device, dtype=torch.float16)
+            k[:, 0, :] *= 3.0                  # SOS-dominant keys, like real prompts
+            cur.append((q, k))
+        sets.append(cur)
+    return sets
+
+
+def one_generation(eng, layers, sets, denoise_steps, latent_side):
+    eng.clear()
+    for t in range(denoise_steps):
+        cur = sets[t % len(sets)]
+        for (layer, heads, side, d), (q, k) in zip(layers, cur):
+            eng.tap_qk(layer, q, k, heads, d ** -0.5, factor=max(0, latent_side // side) if side <= latent_side else 0)
+    eng.flush()
+    return eng.global_heat_map()
+
+
+def tap_bytes(layers, steps_per_launch, acc_bytes, fresh):
+    """Bytes one tap launch must move: conditional-half Q and K of every recorded step, plus
+    one write (and, unless the sums are known to be zero, one read) of the running sums."""
+    qk = sum(heads * side * side * d * 2 + heads * 77 * d * 2 for _, heads, side, d in layers)
+    acc = sum(heads * 77 * side * side * acc_bytes for _, heads, side, d in layers)
+    return steps_per_launch * qk + acc * (1 if fresh else 2), qk, acc
+
+
+def measure_tap_kernel(eng, layers, sets, defer, latent_side, reps):
+    """HIP-event time of back-to-back tap launches (all Q/K pointers recorded first, so the
+    stream sees table upload + kernel only)."""
+    stream = torch.cuda.current_stream()
+    eng.clear()
+    times = []
+    for r in range(reps + 2):
+        for s in range(defer):
+            cur = sets[(r * defer + s) % len(sets)]
+            for (layer, heads, side, d), (q, k) in zip(layers, cur):
+                eng.tap_qk(layer, q, k, heads, d ** -0.5, factor=max(0, latent_side // side) if side <= latent_side else 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        eng.flush()
+        e1.record(stream)
+        e1.synchronize()
+        if r >= 2:                               # first launch after clear() skips the read; warm-up
+            times.append(e0.elapsed_time(e1))
+    return sum(times) / len(times)
+
+
+def measure_finalize(eng, reps):
+    stream = torch.cuda.current_stream()
+    eng.global_heat_map()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        eng.global_heat_map()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def cpu_baseline(kind, latent, denoise_steps, sample_steps=2):
+    """The reference's hook path (torch port, oracle/torch_hooks.py) on the host cores, fp32 (the
+    reference's CPU-runnable configuration): `sample_steps` denoising steps of
+    unravel + per-head update over every hooked layer, and one compute_global_heat_map."""
+    from oracle import torch_hooks as th
+    layers = th.execution_order(th.topology(kind, latent))
+    lat_hw = 4096
+    cores = torch.get_num_threads()
+    cache = {}
+    raw = th.RawMaps()
+    t_tap = 0.0
+    for _ in range(sample_steps):
+        for (layer, heads, side, d) in layers:
+            key = (heads, side)
+            if key not in cache:
+                cache[key] = torch.rand(2 * heads, side * side, 77)
+            t0 = time.perf_counter()
+            th.tap(raw, layer, cache[key], lat_hw)
+            t_tap += time.perf_counter() - t0
+    t0 = time.perf_counter()
+    th.global_heat_map(raw, lat_hw)
+    t_fin = time.perf_counter() - t0
+    per_step = t_tap / sample_steps
+    total = per_step * denoise_steps + t_fin
+    return dict(value=1.0 / total, unit='maps/s', cores=cores, kind='port',
+                ms_per_denoise_step=per_step * 1e3, finalize_s=t_fin,
+                sample=f'{sample_steps} denoising steps x {len(layers)} layers of _unravel_attn+update (fp32, torch '
+                       f'{torch.__version__}, {cores} threads) + 1 compute_global_heat_map over {len(raw)} keys; '
+                       f'extrapolated to {denoise_steps} steps')
+
+
+def eager_gpu_reference(kind, latent, denoise_steps, device, sample_steps=2):
+    """Same port, PyTorch-ROCm eager on the MI355X, fp16 (what the reference does on a GPU)."""
+    from oracle import torch_hooks as th
+    layers = th.execution_order(th.topology(kind, latent))
+    cache = {}
+    for (_, heads, side, _) in layers:
+        if (heads, side) not in cache:
+            cache[(heads, side)] = torch.rand(2 * heads, side * side, 77, device=device).half()
+    raw = th.RawMaps()
+    for (layer, heads, side, d) in layers:                      # warm-up
+        th.tap(raw, layer, cache[(heads, side)], 4096)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(sample_steps):
+        for (layer, heads, side, d) in layers:
+            th.tap(raw, layer, cache[(heads, side)], 4096)
+    torch.cuda.synchronize()
+    per_step = (time.perf_counter() - t0) / sample_steps
+    t0 = time.perf_counter()
+    th.global_heat_map(raw, 4096)
+    torch.cuda.synchronize()
+    t_fin = time.perf_counter() - t0
+    return dict(ms_per_denoise_step=per_step * 1e3, finalize_s=t_fin,
+                maps_per_s=1.0 / (per_step * denoise_steps + t_fin))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20, help='timed generations per rank')
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='sdxl1024', choices=sorted(WORKLOADS))
+    ap.add_argument('--denoise-steps', type=int, default=50)
+    ap.add_argument('--defer', type=int, default=int(os.environ.get('DAAM_DEFER_STEPS', '8')),
+                    help='denoising steps tapped per launch (0 = one launch per layer call)')
+    ap.add_argument('--accumulate', default='exact', choices=['exact', 'float32'])
+    ap.add_argument('--pool', type=int, default=3, help='distinct synthetic Q/K step sets resident in HBM')
+    ap.add_argument('--no-baselines', action='store_true', help='skip the CPU / eager-GPU reference timings')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from daam_amd.engine import HeatMapEngine
+    wl = WORKLOADS[args.workload]
+    layers = topology(wl['kind'], wl['latent'])
+    latent_side = 64
+    sets = make_inputs(layers, args.pool, device, seed=1234 + rank)
+    eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=args.accumulate, defer_steps=args.defer)
+
+    for _ in range(args.warmup):
+        one_generation(eng, layers, sets, args.denoise_steps, latent_side)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    results = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        results.append(one_generation(eng, layers, sets, args.denoise_steps, latent_side))
+    mine = torch.stack(results)
+    if dist:
+        gathered = torch.empty(world * args.steps, *mine.shape[1:], device=device, dtype=mine.dtype)
+        dist.all_gather_into_tensor(gathered, mine)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        acc_bytes = 2 if args.accumulate == 'exact' else 4
+        spl = max(1, args.defer)
+        # ---- roofline of the dominant kernel (tap) ---------------------------------------------
+        if args.defer > 0:
+            tap_ms = measure_tap_kernel(eng, layers, sets, args.defer, latent_side, reps=10)
+            bytes_launch, qk_bytes, acc_total = tap_bytes(layers, spl, acc_bytes, fresh=False)
+            launches_per_gen = -(-args.denoise_steps // spl)
+        else:
+            # immediate mode: 1 launch per layer call; time a whole denoising step of launches
+            stream = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            one_generation(eng, layers, sets, 2, latent_side)
+            e0.record(stream)
+            reps = 10
+            for r in range(reps):
+                for (layer, heads, side, d), (q, k) in zip(layers, sets[r % len(sets)]):
+                    eng.tap_qk(layer, q, k, heads, d ** -0.5, factor=1)
+            e1.record(stream)
+            e1.synchronize()
+            tap_ms = e0.elapsed_time(e1) / reps / len(layers)
+            bytes_launch, qk_bytes, acc_total = tap_bytes(layers, 1, acc_bytes, fresh=False)
+            bytes_launch /= len(layers)
+            launches_per_gen = args.denoise_steps * len(layers)
+        achieved = bytes_launch / (tap_ms * 1e-3) / 1e9
+        survey_bytes = spl * (qk_bytes + 2 * acc_total) if args.defer > 0 else bytes_launch
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+        if os.path.exists(tpath):
+            try:
+                rec = json.load(open(tpath)).get(f'{args.workload}:defer{args.defer}:{args.accumulate}')
+                traffic = rec.get('tap_bytes_per_launch') if rec else None
+            except Exception:
+                traffic = None
+        roofline = dict(bound='hbm', kernel='tap_mfma_kernel<4,half>' if wl['kind'] == 'sdxl' else 'tap_mfma_kernel<*>',
+                        achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
+                        traffic=traffic, bytes_per_launch=int(bytes_launch), ms_per_launch=round(tap_ms, 4),
+                        steps_per_launch=spl, launches_per_generation=launches_per_gen,
+                        achieved_at_survey_8d_bytes=round(survey_bytes / (tap_ms * 1e-3) / 1e9, 1))
+        fin_ms = measure_finalize(eng, reps=20)
+        fin_bytes = acc_total + 77 * 64 * 64 * 4
+        fin_gbs = fin_bytes / (fin_ms * 1e-3) / 1e9
+        gpu_ms_per_gen = launches_per_gen * tap_ms + fin_ms
+        extra = dict(
+            extraction_overhead_ms_per_denoise_step=round((elapsed / args.steps * 1e3) / args.denoise_steps, 4),
+            gpu_ms_per_denoise_step=round(launches_per_gen * tap_ms / args.denoise_steps, 4),
+            gpu_bound_maps_per_s=round(1e3 / gpu_ms_per_gen, 1),
+            raw_maps_per_s=round(world * args.steps * args.denoise_steps * sum(h for _, h, _, _ in layers) / elapsed, 1),
+            roofline_finalize=dict(bound='hbm', kernel='finalize_kernel', achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
+                                   unit='GB/s', frac=round(fin_gbs / HBM_PEAK_GBS, 4), bytes_per_launch=int(fin_bytes),
+                                   ms_per_launch=round(fin_ms, 4)),
+        )
+        eng.close()
+        del sets
+        torch.cuda.empty_cache()
+        cpu = None
+        if not args.no_baselines and world == 1:
+            ref_gpu = eager_gpu_reference(wl['kind'], wl['latent'], args.denoise_steps, device)
+            extra['reference_eager_mi355x'] = {k: round(v, 4) for k, v in ref_gpu.items()}
+            extra['speedup_vs_eager_mi355x'] = round((world * args.steps / elapsed) / ref_gpu['maps_per_s'], 1)
+            cpu = cpu_baseline(wl['kind'], wl['latent'], args.denoise_steps)
+            cpu = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in cpu.items()}
+        out = {
+            'metric': 'heat maps/sec, DAAM extraction (tap + compute_global_heat_map), ' + wl['label'] +
+                      f', {args.denoise_steps}-step, 77-tok',
+            'value': round(world * args.steps / elapsed, 2), 'unit': 'maps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': f'{wl["label"]}, {args.denoise_steps} denoising steps, 77 tokens, CFG batch 2, fp16 Q/K',
+                       'accumulate': args.accumulate, 'defer_steps': args.defer, 'parallelism': f'prompt-shard x{world}',
+                       'generations_per_rank': args.steps},
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        out.update(extra)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

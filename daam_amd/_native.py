@@ -1,0 +1,91 @@
+"""ctypes binding of ``libdaam_hip.so`` (C ABI: ``include/daam_hip.h``).
+
+There is no CPU or PyTorch fallback: if the HIP library is missing or no MI355X is visible
+the import / first call fails loudly.  Build the library with ``python -m daam_amd.build``
+(or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_void_p
+
+LIB_NAME = 'libdaam_hip.so'
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+DAAM_F16, DAAM_F32 = 0, 1
+E_INVALID, E_STATE, E_NOMAPS, E_UNSUPPORTED = -1, -2, -3, -4
+
+# every symbol include/daam_hip.h declares (tests check the library exports exactly these)
+EXPORTS = (
+    'daam_abi_version', 'daam_last_error', 'daam_ctx_create', 'daam_ctx_destroy', 'daam_layer_configure',
+    'daam_layer_acc', 'daam_reset', 'daam_tap_qk', 'daam_tap_qk_enqueue', 'daam_tap_pending', 'daam_tap_flush',
+    'daam_tap_probs', 'daam_key_offset', 'daam_finalize', 'daam_epilogue_normalize', 'daam_word_heat_map',
+    'daam_last_launch',
+)
+
+
+class DaamError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f'libdaam_hip error {code}: {message}')
+        self.code = code
+
+
+class QKDesc(Structure):
+    """``DaamQKDesc`` (include/daam_hip.h)."""
+    _fields_ = [
+        ('in_dtype', c_int32), ('batch', c_int32), ('heads', c_int32), ('hw', c_int32), ('tokens', c_int32),
+        ('head_dim', c_int32), ('round_logits', c_int32), ('scale', c_float),
+        ('q_stride_b', c_int64), ('q_stride_h', c_int64), ('q_stride_p', c_int64),
+        ('k_stride_b', c_int64), ('k_stride_h', c_int64), ('k_stride_t', c_int64),
+    ]
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: the MI355X heat-map path has no fallback. '
+            f'Build it with `python -m daam_amd.build` (needs hipcc, --offload-arch=gfx950).')
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.daam_abi_version.restype = c_int
+    lib.daam_last_error.restype = c_char_p
+    lib.daam_ctx_create.argtypes = [c_int, c_int, c_int, c_int, POINTER(c_void_p)]
+    lib.daam_ctx_destroy.argtypes = [c_void_p]
+    lib.daam_layer_configure.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.daam_layer_acc.argtypes = [c_void_p, c_int, POINTER(c_void_p), POINTER(c_size_t)]
+    lib.daam_reset.argtypes = [c_void_p, c_void_p]
+    lib.daam_tap_qk.argtypes = [c_void_p, c_int, c_void_p, c_void_p, POINTER(QKDesc), c_void_p]
+    lib.daam_tap_qk_enqueue.argtypes = [c_void_p, c_int, c_void_p, c_void_p, POINTER(QKDesc)]
+    lib.daam_tap_pending.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
+    lib.daam_tap_flush.argtypes = [c_void_p, c_void_p]
+    lib.daam_tap_probs.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.daam_key_offset.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]
+    lib.daam_finalize.argtypes = [c_void_p, POINTER(c_uint8), c_void_p, c_void_p]
+    lib.daam_epilogue_normalize.argtypes = [c_void_p, c_int, c_int, c_void_p]
+    lib.daam_word_heat_map.argtypes = [c_void_p, c_int, POINTER(c_int32), c_int, c_void_p, c_void_p, c_int, c_int,
+                                       c_int, c_float, c_void_p, c_void_p]
+    lib.daam_last_launch.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ('daam_last_error',):
+            fn.restype = c_int
+    if lib.daam_abi_version() != 1:
+        raise RuntimeError(f'{LIB_PATH}: ABI version {lib.daam_abi_version()} != 1; rebuild')
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().daam_last_error()
+        raise DaamError(rc, msg.decode() if msg else '')
+
+
+__all__ = ['load', 'check', 'DaamError', 'QKDesc', 'DAAM_F16', 'DAAM_F32', 'EXPORTS', 'LIB_PATH',
+           'byref', 'c_void_p', 'c_int', 'c_uint8', 'c_int32', 'c_size_t', 'E_NOMAPS']

@@ -1,0 +1,600 @@
+// Host side of libdaam_hip.so: the C ABI declared in include/daam_hip.h.
+// Owns no activations; owns (optionally) the running sums, the bicubic tap tables and a
+// small pinned upload ring for the per-launch device tables.
+#include "daam_types.h"
+#include "../../include/daam_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+namespace daam {
+hipError_t launch_tap_generic(const TapLaunch&, int, int, int, hipStream_t, int*, int*);
+hipError_t launch_tap_mfma(const TapLaunch&, int acc_dtype, int max_d, hipStream_t, int*, int*);
+bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t q_sp, int64_t k_st,
+                        int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh);
+int tap_mfma_tile_pixels();
+int tap_mfma_ksteps(int head_dim);
+hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
+hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
+hipError_t launch_normalize(float*, int, int, hipStream_t);
+hipError_t launch_word(const float*, int, const int32_t*, int, float*, float*, int, int, int, float, float*,
+                       hipStream_t);
+}  // namespace daam
+
+using namespace daam;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) return fail((int)_e, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+namespace {
+
+// ---- pinned upload ring -----------------------------------------------------------------
+// alloc() hands out a pinned host region and its device twin; commit() copies it H2D on the
+// stream and, after the consuming kernel has been enqueued, release() records an event so the
+// region is only reused once that kernel has run.  Wrap-around waits (hipEventSynchronize)
+// only if the GPU is more than one ring behind the host.
+struct Ring {
+    static constexpr size_t kBytes = 8u << 20;
+    char* host = nullptr;
+    char* dev = nullptr;
+    size_t head = 0;                  // next free byte
+    struct Busy { size_t begin, end; hipEvent_t ev; };
+    std::deque<Busy> busy;
+    std::vector<hipEvent_t> pool;
+
+    hipError_t init() {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&host), kBytes, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        return hipMalloc(reinterpret_cast<void**>(&dev), kBytes);
+    }
+    void destroy() {
+        for (auto& b : busy) { (void)hipEventSynchronize(b.ev); (void)hipEventDestroy(b.ev); }
+        for (auto ev : pool) (void)hipEventDestroy(ev);
+        busy.clear(); pool.clear();
+        if (host) (void)hipHostFree(host);
+        if (dev) (void)hipFree(dev);
+        host = dev = nullptr;
+    }
+    bool overlaps(size_t b, size_t e) const {
+        for (auto& x : busy) if (b < x.end && x.begin < e) return true;
+        return false;
+    }
+    hipError_t alloc(size_t bytes, size_t* off) {
+        bytes = (bytes + 255) & ~size_t(255);
+        if (bytes > kBytes) return hipErrorOutOfMemory;
+        if (head + bytes > kBytes) head = 0;
+        // retire finished regions; block on the oldest ones still overlapping the request
+        while (!busy.empty() && (hipEventQuery(busy.front().ev) == hipSuccess)) {
+            pool.push_back(busy.front().ev);
+            busy.pop_front();
+        }
+        while (overlaps(head, head + bytes)) {
+            hipError_t e = hipEventSynchronize(busy.front().ev);
+            if (e != hipSuccess) return e;
+            pool.push_back(busy.front().ev);
+            busy.pop_front();
+        }
+        *off = head;
+        head += bytes;
+        cur_begin = *off;
+        cur_end = head;
+        return hipSuccess;
+    }
+    size_t cur_begin = 0, cur_end = 0;
+    hipError_t commit(size_t off, size_t bytes, hipStream_t s) {
+        return hipMemcpyAsync(dev + off, host + off, bytes, hipMemcpyHostToDevice, s);
+    }
+    hipError_t release(hipStream_t s) {
+        hipEvent_t ev;
+        if (!pool.empty()) { ev = pool.back(); pool.pop_back(); }
+        else {
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipEventRecord(ev, s);
+        if (e != hipSuccess) return e;
+        busy.push_back({cur_begin, cur_end, ev});
+        return hipSuccess;
+    }
+};
+
+struct Layer {
+    bool configured = false;
+    int heads = 0, side = 0, hw = 0, factor = 0;
+    void* acc = nullptr;
+    bool owned = false;
+    size_t bytes = 0;
+    int tab = -1;
+    bool dirty = false;      // tapped since the last reset (else the sums are known to be zero)
+};
+
+struct Pending {
+    int layer;
+    const void* q;
+    const void* k;
+    DaamQKDesc d;
+};
+
+constexpr int kMaxTabs = 16;
+
+}  // namespace
+
+struct DaamCtx {
+    int max_layers, tokens, out_side, acc_dtype;
+    std::vector<Layer> layers;
+    Ring ring;
+    int16_t* d_tab_idx = nullptr;
+    float* d_tab_w = nullptr;
+    std::vector<int> tab_sides;
+    std::vector<Pending> pending;
+    int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
+    int force_generic = 0;
+};
+
+static size_t acc_elem(int dtype) { return dtype == DAAM_F16 ? 2 : 4; }
+
+// torch upsample_bicubic2d, align_corners=False, antialias=False:
+// scale = in / out in f32; src = scale * (dst + 0.5) - 0.5 (NOT clamped for cubic);
+// taps floor(src)-1 .. +2 clamped to the border; A = -0.75.
+static void bicubic_table(int in_size, int out_size, int16_t* idx, float* w)
+{
+#pragma clang fp contract(off)
+    const float A = -0.75f;
+    const float scale = (float)in_size / (float)out_size;
+    for (int j = 0; j < out_size; ++j) {
+        const float src = scale * ((float)j + 0.5f) - 0.5f;
+        const float f = std::floor(src);
+        const float t = src - f;
+        const float x0 = t + 1.0f, u = 1.0f - t, x3 = u + 1.0f;
+        w[j * 4 + 0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+        w[j * 4 + 1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+        w[j * 4 + 2] = ((A + 2.0f) * u - (A + 3.0f)) * u * u + 1.0f;
+        w[j * 4 + 3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+        for (int a = 0; a < 4; ++a) {
+            int v = (int)f - 1 + a;
+            v = v < 0 ? 0 : (v > in_size - 1 ? in_size - 1 : v);
+            idx[j * 4 + a] = (int16_t)v;
+        }
+    }
+}
+
+extern "C" {
+
+int daam_abi_version(void) { return DAAM_ABI_VERSION; }
+const char* daam_last_error(void) { return g_err.c_str(); }
+
+int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, DaamCtx** out)
+{
+    if (!out) return fail(DAAM_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (max_layers <= 0 || max_layers > 4096) return fail(DAAM_E_INVALID, "max_layers %d out of range", max_layers);
+    if (tokens <= 0 || tokens > kMaxTokens) return fail(DAAM_E_INVALID, "tokens %d not in 1..%d", tokens, kMaxTokens);
+    if (out_side <= 0 || out_side > 128) return fail(DAAM_E_INVALID, "out_side %d not in 1..128", out_side);
+    if (acc_dtype != DAAM_F16 && acc_dtype != DAAM_F32) return fail(DAAM_E_INVALID, "acc_dtype %d", acc_dtype);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail((int)hipErrorNoDevice, "no HIP device");
+    DaamCtx* c = new DaamCtx();
+    c->max_layers = max_layers;
+    c->tokens = tokens;
+    c->out_side = out_side;
+    c->acc_dtype = acc_dtype;
+    c->layers.resize(max_layers);
+    hipError_t e = c->ring.init();
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_tab_idx), sizeof(int16_t) * kMaxTabs * out_side * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_tab_w), sizeof(float) * kMaxTabs * out_side * 4);
+    if (e != hipSuccess) {
+        daam_ctx_destroy(c);
+        return fail((int)e, "context allocation: %s", hipGetErrorString(e));
+    }
+    const char* fg = getenv("DAAM_FORCE_GENERIC");
+    c->force_generic = fg && fg[0] == '1';
+    *out = c;
+    return 0;
+}
+
+int daam_ctx_destroy(DaamCtx* c)
+{
+    if (!c) return 0;
+    (void)hipDeviceSynchronize();
+    c->ring.destroy();
+    for (auto& l : c->layers)
+        if (l.owned && l.acc) (void)hipFree(l.acc);
+    if (c->d_tab_idx) (void)hipFree(c->d_tab_idx);
+    if (c->d_tab_w) (void)hipFree(c->d_tab_w);
+    delete c;
+    return 0;
+}
+
+int daam_layer_configure(DaamCtx* c, int layer, int heads, int side, int factor, void* acc)
+{
+    if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
+    if (layer < 0 || layer >= c->max_layers) return fail(DAAM_E_INVALID, "layer %d out of range", layer);
+    if (heads <= 0 || side <= 0 || side > 1024) return fail(DAAM_E_INVALID, "heads %d / side %d", heads, side);
+    for (auto& p : c->pending)
+        if (p.layer == layer) return fail(DAAM_E_STATE, "layer %d re-configured with un-flushed taps pending", layer);
+    Layer& l = c->layers[layer];
+    if (l.owned && l.acc) { HIP_TRY(hipFree(l.acc)); }
+    l = Layer();
+    l.heads = heads;
+    l.side = side;
+    l.hw = side * side;
+    l.factor = factor;
+    l.bytes = (size_t)heads * c->tokens * l.hw * acc_elem(c->acc_dtype);
+    if (acc) {
+        l.acc = acc;
+    } else {
+        HIP_TRY(hipMalloc(&l.acc, l.bytes));
+        HIP_TRY(hipMemset(l.acc, 0, l.bytes));
+        l.owned = true;
+    }
+    if (side != c->out_side) {
+        int tab = -1;
+        for (size_t i = 0; i < c->tab_sides.size(); ++i)
+            if (c->tab_sides[i] == side) tab = (int)i;
+        if (tab < 0) {
+            if ((int)c->tab_sides.size() >= kMaxTabs) return fail(DAAM_E_UNSUPPORTED, "more than %d distinct map sizes", kMaxTabs);
+            tab = (int)c->tab_sides.size();
+            std::vector<int16_t> idx(c->out_side * 4);
+            std::vector<float> w(c->out_side * 4);
+            bicubic_table(side, c->out_side, idx.data(), w.data());
+            HIP_TRY(hipMemcpy(c->d_tab_idx + (size_t)tab * c->out_side * 4, idx.data(), idx.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_tab_w + (size_t)tab * c->out_side * 4, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+            c->tab_sides.push_back(side);
+        }
+        l.tab = tab;
+    }
+    l.configured = true;
+    return 0;
+}
+
+int daam_layer_acc(DaamCtx* c, int layer, void** acc, size_t* bytes)
+{
+    if (!c || layer < 0 || layer >= c->max_layers || !c->layers[layer].configured)
+        return fail(DAAM_E_STATE, "layer %d not configured", layer);
+    if (acc) *acc = c->layers[layer].acc;
+    if (bytes) *bytes = c->layers[layer].bytes;
+    return 0;
+}
+
+int daam_reset(DaamCtx* c, void* stream)
+{
+    if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
+    c->pending.clear();
+    for (auto& l : c->layers)
+        if (l.configured) {
+            HIP_TRY(hipMemsetAsync(l.acc, 0, l.bytes, (hipStream_t)stream));
+            l.dirty = false;
+        }
+    return 0;
+}
+
+static int check_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQKDesc* d)
+{
+    if (!c || !d || !q || !k) return fail(DAAM_E_INVALID, "NULL argument");
+    if (layer < 0 || layer >= c->max_layers || !c->layers[layer].configured)
+        return fail(DAAM_E_STATE, "layer %d not configured", layer);
+    const Layer& l = c->layers[layer];
+    if (d->in_dtype != DAAM_F16 && d->in_dtype != DAAM_F32) return fail(DAAM_E_INVALID, "in_dtype %d", d->in_dtype);
+    if (d->in_dtype == DAAM_F32 && c->acc_dtype == DAAM_F16)
+        return fail(DAAM_E_INVALID, "fp32 activations need fp32 running sums");
+    if (d->tokens != c->tokens) return fail(DAAM_E_INVALID, "tokens %d != context size %d (reference gate, trace.py:289)", d->tokens, c->tokens);
+    if (d->batch <= 0 || d->heads <= 0 || d->head_dim <= 0 || d->head_dim > 1024)
+        return fail(DAAM_E_INVALID, "batch %d heads %d head_dim %d", d->batch, d->heads, d->head_dim);
+    const int bh = d->batch * d->heads;
+    if (bh - bh / 2 != l.heads) return fail(DAAM_E_INVALID, "layer %d holds %d heads, call keeps %d", layer, l.heads, bh - bh / 2);
+    if (d->hw != l.hw) return fail(DAAM_E_INVALID, "layer %d holds %d positions, call has %d", layer, l.hw, d->hw);
+    return 0;
+}
+
+static void fill_layer(const DaamCtx* c, const Layer& l, const DaamQKDesc& d, int tile_pixels, TapLayer* t)
+{
+    const int bh = d.batch * d.heads;
+    t->acc = l.acc;
+    t->heads_kept = l.heads;
+    t->bh_first = bh / 2;
+    t->heads = d.heads;
+    t->hw = d.hw;
+    t->head_dim = d.head_dim;
+    t->tiles_per_head = (d.hw + tile_pixels - 1) / tile_pixels;
+    t->wg_begin = 0;
+    t->n_steps = 1;
+    t->ptr_begin = 0;
+    t->round_logits = d.round_logits;
+    t->scale = d.scale;
+    t->fresh = l.dirty ? 0 : 1;
+    t->q_sb = d.q_stride_b; t->q_sh = d.q_stride_h; t->q_sp = d.q_stride_p;
+    t->k_sb = d.k_stride_b; t->k_sh = d.k_stride_h; t->k_st = d.k_stride_t;
+    (void)c;
+}
+
+static bool use_mfma(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
+{
+    if (c->force_generic) return false;
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) return false;
+    return tap_mfma_supported(d.in_dtype, d.head_dim, d.tokens, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b,
+                              d.q_stride_h, d.k_stride_b, d.k_stride_h);
+}
+
+int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQKDesc* d, void* stream)
+{
+    int rc = check_qk(c, layer, q, k, d);
+    if (rc) return rc;
+    if (!c->pending.empty()) return fail(DAAM_E_STATE, "immediate tap with deferred taps pending: flush first");
+    const bool mfma = use_mfma(c, *d, q, k);
+    TapLaunch L;
+    memset(&L, 0, sizeof L);
+    fill_layer(c, c->layers[layer], *d, mfma ? tap_mfma_tile_pixels() : kTapPixels, &L.one);
+    L.one_ptr.q = q;
+    L.one_ptr.k = k;
+    L.n_layers = 1;
+    L.tokens = c->tokens;
+    L.total_wgs = L.one.heads_kept * L.one.tiles_per_head;
+    L.wgs_per_xcd = (L.total_wgs + 7) / 8;
+    c->last_block[0] = 256;
+    hipError_t e = mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+                        : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
+                                             &c->last_grid[0], &c->last_lds[0]);
+    if (e != hipSuccess) return fail((int)e, "tap launch: %s", hipGetErrorString(e));
+    c->layers[layer].dirty = true;
+    return 0;
+}
+
+int daam_tap_qk_enqueue(DaamCtx* c, int layer, const void* q, const void* k, const DaamQKDesc* d)
+{
+    int rc = check_qk(c, layer, q, k, d);
+    if (rc) return rc;
+    if (!c->pending.empty()) {
+        if (c->pending.front().d.in_dtype != d->in_dtype)
+            return fail(DAAM_E_STATE, "mixed activation dtypes in one deferred batch: flush first");
+        // every recorded step of a layer must share shape and strides
+        for (auto it = c->pending.rbegin(); it != c->pending.rend(); ++it) {
+            if (it->layer != layer) continue;
+            const DaamQKDesc& o = it->d;
+            if (o.batch != d->batch || o.heads != d->heads || o.head_dim != d->head_dim ||
+                o.round_logits != d->round_logits || o.scale != d->scale || o.q_stride_b != d->q_stride_b ||
+                o.q_stride_h != d->q_stride_h || o.q_stride_p != d->q_stride_p || o.k_stride_b != d->k_stride_b ||
+                o.k_stride_h != d->k_stride_h || o.k_stride_t != d->k_stride_t)
+                return fail(DAAM_E_STATE, "layer %d changed shape inside a deferred batch: flush first", layer);
+            break;
+        }
+    }
+    c->pending.push_back({layer, q, k, *d});
+    return 0;
+}
+
+int daam_tap_pending(DaamCtx* c, int* n_calls, int* max_steps)
+{
+    if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
+    std::vector<int> cnt(c->max_layers, 0);
+    int mx = 0;
+    for (auto& p : c->pending) mx = std::max(mx, ++cnt[p.layer]);
+    if (n_calls) *n_calls = (int)c->pending.size();
+    if (max_steps) *max_steps = mx;
+    return 0;
+}
+
+int daam_tap_flush(DaamCtx* c, void* stream)
+{
+    if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
+    if (c->pending.empty()) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int in_dtype = c->pending.front().d.in_dtype;
+    // group the recorded calls by layer (first-seen order, steps in recorded order), and the
+    // layers by kernel: MFMA k-step count ceil(d/16), or 0 = generic kernel.
+    std::vector<int> order;
+    std::vector<int> slot(c->max_layers, -1);
+    std::vector<std::vector<const Pending*>> per;
+    std::vector<int> kind;
+    for (auto& p : c->pending) {
+        if (slot[p.layer] < 0) {
+            slot[p.layer] = (int)order.size();
+            order.push_back(p.layer);
+            per.emplace_back();
+            kind.push_back(tap_mfma_ksteps(p.d.head_dim));
+        }
+        const int i = slot[p.layer];
+        if (!use_mfma(c, p.d, p.q, p.k)) kind[i] = 0;
+        per[i].push_back(&p);
+    }
+    std::vector<int> kinds;
+    for (int kd : kind)
+        if (std::find(kinds.begin(), kinds.end(), kd) == kinds.end()) kinds.push_back(kd);
+    int rc = 0;
+    int grid_total = 0;
+    for (int kd : kinds) {
+        size_t n_layers = 0, n_ptrs = 0;
+        for (size_t i = 0; i < order.size(); ++i)
+            if (kind[i] == kd) { ++n_layers; n_ptrs += per[i].size(); }
+        const int tile = kd ? tap_mfma_tile_pixels() : kTapPixels;
+        const size_t bytes_layers = n_layers * sizeof(TapLayer), bytes = bytes_layers + n_ptrs * sizeof(TapPtr);
+        size_t off = 0;
+        hipError_t e = c->ring.alloc(bytes, &off);
+        if (e != hipSuccess) { rc = fail((int)e, "upload ring: %s", hipGetErrorString(e)); break; }
+        TapLayer* hl = reinterpret_cast<TapLayer*>(c->ring.host + off);
+        TapPtr* hp = reinterpret_cast<TapPtr*>(c->ring.host + off + bytes_layers);
+        int wg = 0, ptr = 0, max_d = 0;
+        size_t j = 0;
+        for (size_t i = 0; i < order.size(); ++i) {
+            if (kind[i] != kd) continue;
+            const auto& v = per[i];
+            fill_layer(c, c->layers[order[i]], v[0]->d, tile, &hl[j]);
+            hl[j].wg_begin = wg;
+            hl[j].n_steps = (int)v.size();
+            hl[j].ptr_begin = ptr;
+            for (auto* p : v) { hp[ptr].q = p->q; hp[ptr].k = p->k; ++ptr; }
+            wg += hl[j].heads_kept * hl[j].tiles_per_head;
+            max_d = std::max(max_d, v[0]->d.head_dim);
+            ++j;
+        }
+        e = c->ring.commit(off, bytes, s);
+        if (e != hipSuccess) { rc = fail((int)e, "table upload: %s", hipGetErrorString(e)); break; }
+        TapLaunch L;
+        memset(&L, 0, sizeof L);
+        L.layers = reinterpret_cast<const TapLayer*>(c->ring.dev + off);
+        L.ptrs = reinterpret_cast<const TapPtr*>(c->ring.dev + off + bytes_layers);
+        L.n_layers = (int)n_layers;
+        L.tokens = c->tokens;
+        L.total_wgs = wg;
+        L.wgs_per_xcd = (wg + 7) / 8;
+        int grid = 0;
+        e = kd ? launch_tap_mfma(L, c->acc_dtype, max_d, s, &grid, &c->last_lds[0])
+               : launch_tap_generic(L, in_dtype, c->acc_dtype, max_d, s, &grid, &c->last_lds[0]);
+        grid_total += grid;
+        if (e != hipSuccess) { rc = fail((int)e, "tap launch: %s", hipGetErrorString(e)); break; }
+        e = c->ring.release(s);
+        if (e != hipSuccess) { rc = fail((int)e, "event record: %s", hipGetErrorString(e)); break; }
+        for (size_t i = 0; i < order.size(); ++i)
+            if (kind[i] == kd) c->layers[order[i]].dirty = true;
+    }
+    c->last_grid[0] = grid_total;
+    c->last_block[0] = 256;
+    c->pending.clear();
+    return rc;
+}
+
+int daam_tap_probs(DaamCtx* c, int layer, const void* probs, int in_dtype, int batch_heads, int hw, int tokens,
+                   void* stream)
+{
+    if (!c || !probs) return fail(DAAM_E_INVALID, "NULL argument");
+    if (layer < 0 || layer >= c->max_layers || !c->layers[layer].configured)
+        return fail(DAAM_E_STATE, "layer %d not configured", layer);
+    if (!c->pending.empty()) return fail(DAAM_E_STATE, "probs tap with deferred taps pending: flush first");
+    const Layer& l = c->layers[layer];
+    if (in_dtype != DAAM_F16 && in_dtype != DAAM_F32) return fail(DAAM_E_INVALID, "in_dtype %d", in_dtype);
+    if (in_dtype == DAAM_F32 && c->acc_dtype == DAAM_F16) return fail(DAAM_E_INVALID, "fp32 probabilities need fp32 running sums");
+    if (tokens != c->tokens) return fail(DAAM_E_INVALID, "tokens %d != context size %d", tokens, c->tokens);
+    if (batch_heads - batch_heads / 2 != l.heads || hw != l.hw)
+        return fail(DAAM_E_INVALID, "layer %d is [%d heads, %d positions], call has [%d kept, %d]", layer, l.heads, l.hw,
+                    batch_heads - batch_heads / 2, hw);
+    ProbsLaunch L;
+    L.acc = l.acc;
+    L.probs = probs;
+    L.heads_kept = l.heads;
+    L.bh_first = batch_heads / 2;
+    L.hw = hw;
+    L.tokens = tokens;
+    L.tiles_per_head = (hw + kTapPixels - 1) / kTapPixels;
+    L.total_wgs = L.heads_kept * L.tiles_per_head;
+    L.wgs_per_xcd = (L.total_wgs + 7) / 8;
+    c->last_block[0] = 256;
+    hipError_t e = launch_tap_probs(L, in_dtype, c->acc_dtype, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0]);
+    if (e != hipSuccess) return fail((int)e, "probs tap launch: %s", hipGetErrorString(e));
+    c->layers[layer].dirty = true;
+    return 0;
+}
+
+int daam_key_offset(DaamCtx* c, int layer, int* offset, int* total)
+{
+    if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
+    int off = 0, tot = 0;
+    for (int i = 0; i < c->max_layers; ++i) {
+        if (i == layer) off = tot;
+        if (c->layers[i].configured) tot += c->layers[i].heads;
+    }
+    if (offset) *offset = off;
+    if (total) *total = tot;
+    return 0;
+}
+
+int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
+{
+    if (!c || !out) return fail(DAAM_E_INVALID, "NULL argument");
+    if (!c->pending.empty()) return fail(DAAM_E_STATE, "finalize with deferred taps pending: flush first");
+    std::vector<FinKey> keys;
+    int pos = 0, max_side = 0;
+    for (int i = 0; i < c->max_layers; ++i) {
+        const Layer& l = c->layers[i];
+        if (!l.configured) continue;
+        for (int h = 0; h < l.heads; ++h, ++pos) {
+            if (key_mask && !key_mask[pos]) continue;
+            FinKey k;
+            k.base = static_cast<const char*>(l.acc) + (size_t)h * c->tokens * l.hw * acc_elem(c->acc_dtype);
+            k.side = l.side;
+            k.tab = l.tab;
+            if (l.tab >= 0) max_side = std::max(max_side, l.side);
+            keys.push_back(k);
+        }
+    }
+    if (keys.empty()) return fail(DAAM_E_NOMAPS, "no heat maps selected");
+    if (max_side > 128) return fail(DAAM_E_UNSUPPORTED, "map side %d > 128 not supported by finalize", max_side);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t plane = (size_t)c->out_side * c->out_side;
+    HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * c->tokens * plane, s));
+    size_t off = 0;
+    const size_t bytes = keys.size() * sizeof(FinKey);
+    HIP_TRY(c->ring.alloc(bytes, &off));
+    memcpy(c->ring.host + off, keys.data(), bytes);
+    HIP_TRY(c->ring.commit(off, bytes, s));
+    FinLaunch L;
+    L.keys = reinterpret_cast<const FinKey*>(c->ring.dev + off);
+    L.tab_idx = c->d_tab_idx;
+    L.tab_w = c->d_tab_w;
+    L.out = out;
+    L.n_keys = (int)keys.size();
+    L.n_chunks = std::max(1, std::min(L.n_keys, 32));
+    L.tokens = c->tokens;
+    L.out_side = c->out_side;
+    L.inv_n = 1.0f / (float)L.n_keys;
+    L.max_side = max_side;
+    c->last_block[1] = 256;
+    hipError_t e = launch_finalize(L, c->acc_dtype, s, &c->last_grid[1], &c->last_lds[1]);
+    if (e != hipSuccess) return fail((int)e, "finalize launch: %s", hipGetErrorString(e));
+    HIP_TRY(c->ring.release(s));
+    return 0;
+}
+
+int daam_epilogue_normalize(float* maps, int n_rows, int side, void* stream)
+{
+    if (!maps || n_rows <= 0 || side <= 0) return fail(DAAM_E_INVALID, "bad argument");
+    hipError_t e = launch_normalize(maps, n_rows, side * side, (hipStream_t)stream);
+    if (e != hipSuccess) return fail((int)e, "normalize launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int daam_word_heat_map(const float* maps, int side, const int32_t* idx, int n_idx, float* word_map, float* out,
+                       int out_h, int out_w, int absolute, float threshold, float* workspace, void* stream)
+{
+    if (!maps || !idx || !word_map || !workspace) return fail(DAAM_E_INVALID, "NULL argument");
+    if (n_idx <= 0 || n_idx > kMaxTokens) return fail(DAAM_E_INVALID, "n_idx %d not in 1..%d", n_idx, kMaxTokens);
+    if (side <= 0 || (out && (out_h <= 0 || out_w <= 0))) return fail(DAAM_E_INVALID, "bad size");
+    hipError_t e = launch_word(maps, side, idx, n_idx, word_map, out, out_h, out_w, absolute, threshold, workspace,
+                               (hipStream_t)stream);
+    if (e != hipSuccess) return fail((int)e, "word map launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int daam_last_launch(DaamCtx* c, int which, int* grid, int* block, int* lds_bytes)
+{
+    if (!c || which < 0 || which > 1) return fail(DAAM_E_INVALID, "bad argument");
+    if (grid) *grid = c->last_grid[which];
+    if (block) *block = c->last_block[which];
+    if (lds_bytes) *lds_bytes = c->last_lds[which];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,446 @@
+// Baseline (any head_dim, any dtype combo) kernels of the DAAM heat-map extraction path for
+// gfx950.  The fp16 MFMA tap lives in daam_tap_mfma.hip; this file holds
+//   * tap_generic_kernel   : softmax(scale q k^T) -> conditional half -> running sums
+//                            (reference daam/trace.py:276-294 + daam/heatmap.py:153-156)
+//   * tap_probs_kernel     : the same accumulate from materialised probabilities
+//   * finalize_kernel      : bicubic -> clamp -> mean over keys (daam/trace.py:112-126)
+//   * normalize_kernel     : daam/trace.py:129-130
+//   * word map kernels     : daam/heatmap.py:121-123, 77-93
+#include "daam_types.h"
+
+namespace daam {
+
+// ---------------------------------------------------------------------------------------
+// dtype helpers.  "round_to<T>" reproduces the rounding point of a tensor that the reference
+// pipeline materialises in dtype T (fp16 logits / probabilities), returning the value as f32.
+// ---------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<__half>(const __half* p) { return __half2float(*p); }
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+
+template <typename T> __device__ __forceinline__ float round_to(float x);
+template <> __device__ __forceinline__ float round_to<__half>(float x) { return __half2float(__float2half_rn(x)); }
+template <> __device__ __forceinline__ float round_to<float>(float x) { return x; }
+
+// acc = acc + x in the accumulator dtype.  For fp16 the f32 add of two fp16 values followed by
+// one RNE rounding is the correctly rounded fp16 add (24 >= 2*11+2 bits), i.e. exactly what
+// torch's / numpy's half add does (heatmap.py:156).
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<__half>(__half* p, float v) { *p = __float2half_rn(v); }
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+
+// XCD-aware block remap: hardware places block b on XCD b % 8; give each XCD a contiguous
+// range of logical tiles so the tiles of one (layer, head) - which share K - share an L2.
+__device__ __forceinline__ int logical_block(int total_wgs, int wgs_per_xcd) {
+    const int b = blockIdx.x;
+    const int l = (b & 7) * wgs_per_xcd + (b >> 3);
+    return l < total_wgs ? l : -1;
+}
+
+__device__ __forceinline__ int find_layer(const TapLayer* layers, int n, int wg) {
+    int lo = 0, hi = n - 1;                       // last layer with wg_begin <= wg
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (layers[mid].wg_begin <= wg) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------
+// Generic tap.  256 threads = 64 pixels x 4 token chunks.  Thread (p, part) owns the running
+// sums acc[t][p0 + p] for its <= 20 tokens in registers across every step of the launch.
+// LDS: K of the current (step, head) as f32 [tokens][d] (broadcast reads), plus the
+// cross-chunk softmax reductions.
+// ---------------------------------------------------------------------------------------
+template <typename IN_T, typename ACC_T>
+__global__ __launch_bounds__(256) void tap_generic_kernel(const TapLaunch L)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int wg = logical_block(L.total_wgs, L.wgs_per_xcd);
+    if (wg < 0) return;
+
+    TapLayer lay;
+    const TapPtr* ptrs;
+    if (L.layers) {
+        lay = L.layers[find_layer(L.layers, L.n_layers, wg)];
+        ptrs = L.ptrs + lay.ptr_begin;
+    } else {
+        lay = L.one;
+        ptrs = &L.one_ptr;
+    }
+    const int tokens = L.tokens;
+    const int d = lay.head_dim;
+    const int rel = wg - lay.wg_begin;
+    const int kh = rel / lay.tiles_per_head;              // kept-head index 0..heads_kept-1
+    const int p0 = (rel - kh * lay.tiles_per_head) * kTapPixels;
+    const int bh = lay.bh_first + kh;
+    const int b = bh / lay.heads, h = bh - b * lay.heads;
+
+    float* Ks = reinterpret_cast<float*>(smem_raw);        // [tokens][d]
+    float* red = Ks + tokens * d;                          // [2][kTapParts][kTapPixels]
+
+    const int tid = threadIdx.x;
+    const int p = tid & (kTapPixels - 1);
+    const int part = tid >> 6;
+    const int pixel = p0 + p;
+    const bool valid = pixel < lay.hw;
+    const int t0 = part * kTokPerPart;
+    const int nt = min(kTokPerPart, tokens - t0);          // may be <= 0 for tiny token counts
+
+    ACC_T* acc = reinterpret_cast<ACC_T*>(lay.acc) + (size_t)kh * tokens * lay.hw;
+    float run[kTokPerPart];
+#pragma unroll
+    for (int i = 0; i < kTokPerPart; ++i)
+        run[i] = (valid && i < nt) ? ld<ACC_T>(acc + (size_t)(t0 + i) * lay.hw + pixel) : 0.f;
+
+    for (int s = 0; s < lay.n_steps; ++s) {
+        const IN_T* q = reinterpret_cast<const IN_T*>(ptrs[s].q) + b * lay.q_sb + h * lay.q_sh;
+        const IN_T* k = reinterpret_cast<const IN_T*>(ptrs[s].k) + b * lay.k_sb + h * lay.k_sh;
+        __syncthreads();                                   // previous step done with Ks / red
+        for (int i = tid; i < tokens * d; i += 256) {
+            const int t = i / d, dd = i - t * d;
+            Ks[i] = ld<IN_T>(k + t * lay.k_st + dd);
+        }
+        __syncthreads();
+
+        float logit[kTokPerPart];
+#pragma unroll
+        for (int i = 0; i < kTokPerPart; ++i) logit[i] = 0.f;
+        if (valid) {
+            const IN_T* qrow = q + (int64_t)pixel * lay.q_sp;
+            for (int dd = 0; dd < d; ++dd) {
+                const float qv = ld<IN_T>(qrow + dd);
+#pragma unroll
+                for (int i = 0; i < kTokPerPart; ++i)
+                    if (i < nt) logit[i] = fmaf(qv, Ks[(t0 + i) * d + dd], logit[i]);
+            }
+        }
+        // alpha applied in f32 to the f32 dot product, then the baddbmm output rounding
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < kTokPerPart; ++i) {
+            float x = logit[i] * lay.scale;
+            if (lay.round_logits) x = round_to<IN_T>(x);
+            logit[i] = x;
+            if (i < nt) m = fmaxf(m, x);
+        }
+        red[part * kTapPixels + p] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[p], red[kTapPixels + p]), fmaxf(red[2 * kTapPixels + p], red[3 * kTapPixels + p]));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < kTokPerPart; ++i) {
+            const float e = (i < nt) ? expf(logit[i] - m) : 0.f;
+            logit[i] = e;
+            sum += e;
+        }
+        float* rsum = red + kTapParts * kTapPixels;
+        rsum[part * kTapPixels + p] = sum;
+        __syncthreads();
+        sum = (rsum[p] + rsum[kTapPixels + p]) + (rsum[2 * kTapPixels + p] + rsum[3 * kTapPixels + p]);
+#pragma unroll
+        for (int i = 0; i < kTokPerPart; ++i) {
+            const float prob = round_to<IN_T>(logit[i] / sum);       // probs.to(dtype)
+            run[i] = round_to<ACC_T>(run[i] + prob);                  // heatmap.py:156
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < kTokPerPart; ++i)
+            if (i < nt) st<ACC_T>(acc + (size_t)(t0 + i) * lay.hw + pixel, run[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Tap from materialised probabilities [BH, hw, tokens] (contiguous).  The 64-pixel chunk of
+// one head is one contiguous run of 64*tokens elements: stage it through LDS with coalesced
+// reads, then the same (pixel, token-chunk) ownership as above does the transposed add.
+// ---------------------------------------------------------------------------------------
+template <typename IN_T, typename ACC_T>
+__global__ __launch_bounds__(256) void tap_probs_kernel(const ProbsLaunch L)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int wg = logical_block(L.total_wgs, L.wgs_per_xcd);
+    if (wg < 0) return;
+    const int tokens = L.tokens;
+    const int kh = wg / L.tiles_per_head;
+    const int p0 = (wg - kh * L.tiles_per_head) * kTapPixels;
+    const int npix = min(kTapPixels, L.hw - p0);
+    IN_T* raw = reinterpret_cast<IN_T*>(smem_raw);         // [npix][tokens]
+    const IN_T* src = reinterpret_cast<const IN_T*>(L.probs) + ((size_t)(L.bh_first + kh) * L.hw + p0) * tokens;
+    const int tid = threadIdx.x;
+    const int n = npix * tokens;
+    for (int i = tid; i < n; i += 256) raw[i] = src[i];
+    __syncthreads();
+    const int p = tid & (kTapPixels - 1);
+    const int part = tid >> 6;
+    if (p >= npix) return;
+    const int t0 = part * kTokPerPart;
+    const int nt = min(kTokPerPart, tokens - t0);
+    ACC_T* acc = reinterpret_cast<ACC_T*>(L.acc) + (size_t)kh * tokens * L.hw + (p0 + p);
+    for (int i = 0; i < nt; ++i) {
+        ACC_T* a = acc + (size_t)(t0 + i) * L.hw;
+        st<ACC_T>(a, ld<ACC_T>(a) + ld<IN_T>(raw + p * tokens + t0 + i));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Finalize: grid (tokens, n_chunks).  Workgroup (t, c) walks keys c, c + n_chunks, ... :
+// plane -> LDS (f32) -> x pass -> y pass -> clamp -> += LDS out tile; one f32 atomicAdd per
+// output element per workgroup at the end (scaled by 1 / n_keys).
+// Separable in the same order as torch's upsample_bicubic2d (x on the 4 source rows, then y).
+// ---------------------------------------------------------------------------------------
+template <typename ACC_T>
+__global__ __launch_bounds__(256) void finalize_kernel(const FinLaunch L)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tok = blockIdx.x;
+    const int chunk = blockIdx.y;
+    const int O = L.out_side;
+    float* outt = reinterpret_cast<float*>(smem_raw);            // [O][O]
+    float* plane = outt + O * O;                                 // [max_side][max_side]
+    float* tmp = plane + L.max_side * L.max_side;                // [max_side][O]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < O * O; i += 256) outt[i] = 0.f;
+
+    for (int kidx = chunk; kidx < L.n_keys; kidx += L.n_chunks) {
+        const FinKey key = L.keys[kidx];
+        const int S = key.side;
+        const ACC_T* src = reinterpret_cast<const ACC_T*>(key.base) + (size_t)tok * S * S;
+        if (key.tab < 0) {                                       // same size: copy (+ clamp)
+            for (int i = tid; i < O * O; i += 256) outt[i] += fmaxf(ld<ACC_T>(src + i), 0.f);
+            continue;
+        }
+        const int16_t* tix = L.tab_idx + (size_t)key.tab * O * 4;
+        const float* tw = L.tab_w + (size_t)key.tab * O * 4;
+        __syncthreads();                                         // previous key done with plane/tmp
+        for (int i = tid; i < S * S; i += 256) plane[i] = ld<ACC_T>(src + i);
+        __syncthreads();
+        for (int i = tid; i < S * O; i += 256) {
+            const int y = i / O, ox = i - y * O;
+            const float* row = plane + y * S;
+            const int16_t* ix = tix + ox * 4;
+            const float* w = tw + ox * 4;
+            tmp[i] = row[ix[0]] * w[0] + row[ix[1]] * w[1] + row[ix[2]] * w[2] + row[ix[3]] * w[3];
+        }
+        __syncthreads();
+        for (int i = tid; i < O * O; i += 256) {
+            const int oy = i / O, ox = i - oy * O;
+            const int16_t* iy = tix + oy * 4;
+            const float* w = tw + oy * 4;
+            const float v = tmp[iy[0] * O + ox] * w[0] + tmp[iy[1] * O + ox] * w[1] +
+                            tmp[iy[2] * O + ox] * w[2] + tmp[iy[3] * O + ox] * w[3];
+            outt[i] += fmaxf(v, 0.f);
+        }
+    }
+    // each thread only ever touched its own outt[i] entries (i = tid mod 256): no barrier needed
+    float* out = L.out + (size_t)tok * O * O;
+    for (int i = tid; i < O * O; i += 256) atomicAdd(out + i, outt[i] * L.inv_n);
+}
+
+// trace.py:129-130  maps[:n] / (maps[1:n-1].sum(0) + 1e-6)
+__global__ __launch_bounds__(256) void normalize_kernel(float* maps, int n_rows, int plane)
+{
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= plane) return;
+    float s = 0.f;
+    for (int t = 1; t < n_rows - 1; ++t) s += maps[(size_t)t * plane + px];
+    s += 1e-6f;
+    for (int t = 0; t < n_rows; ++t) maps[(size_t)t * plane + px] /= s;
+}
+
+// ---------------------------------------------------------------------------------------
+// Word heat map (heatmap.py:121-123) and expand_as (heatmap.py:77-93).
+// ---------------------------------------------------------------------------------------
+struct WordIdx { int32_t n; int32_t idx[kMaxTokens]; };
+
+__global__ __launch_bounds__(256) void word_mean_kernel(const float* maps, int plane, WordIdx w, float* word_map,
+                                                        float* minmax)
+{
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // order-preserving int encodings of +inf / -inf for the atomicMin / atomicMax below
+        reinterpret_cast<int*>(minmax)[0] = 0x7f800000;
+        reinterpret_cast<int*>(minmax)[1] = (int)0x80000000 ^ 0x7fffffff ^ 0x7f800000;   // enc(-inf)
+    }
+    if (px >= plane) return;
+    float s = 0.f;
+    for (int i = 0; i < w.n; ++i) s += maps[(size_t)w.idx[i] * plane + px];
+    word_map[px] = s / (float)w.n;
+}
+
+__device__ __forceinline__ int enc_ordered(float f) {
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float dec_ordered(int i) {
+    return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
+}
+
+__device__ __forceinline__ void cubic_coeffs(float t, float w[4]) {
+#pragma clang fp contract(off)
+    const float A = -0.75f;
+    const float x0 = t + 1.0f;
+    w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    w[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+    const float u = 1.0f - t;
+    w[2] = ((A + 2.0f) * u - (A + 3.0f)) * u * u + 1.0f;
+    const float x3 = u + 1.0f;
+    w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+// one thread per output pixel; source plane (<= 96x96 f32) is L1/L2 resident
+__global__ __launch_bounds__(256) void word_expand_kernel(const float* word_map, int side, float* out, int out_h,
+                                                          int out_w, float* minmax)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    const bool valid = i < out_h * out_w;
+    if (valid) {
+        const int oy = i / out_w, ox = i - oy * out_w;
+        float wy[4], wx[4];
+        int iy[4], ix[4];
+        {
+            const float sc = (float)side / (float)out_h;
+            const float src = sc * ((float)oy + 0.5f) - 0.5f;
+            const float f = floorf(src);
+            cubic_coeffs(src - f, wy);
+            for (int a = 0; a < 4; ++a) iy[a] = min(max((int)f - 1 + a, 0), side - 1);
+        }
+        {
+            const float sc = (float)side / (float)out_w;
+            const float src = sc * ((float)ox + 0.5f) - 0.5f;
+            const float f = floorf(src);
+            cubic_coeffs(src - f, wx);
+            for (int a = 0; a < 4; ++a) ix[a] = min(max((int)f - 1 + a, 0), side - 1);
+        }
+        if (side == out_h && side == out_w) {
+            v = word_map[i];
+        } else {
+            float rows[4];
+            for (int a = 0; a < 4; ++a) {
+                const float* r = word_map + iy[a] * side;
+                rows[a] = r[ix[0]] * wx[0] + r[ix[1]] * wx[1] + r[ix[2]] * wx[2] + r[ix[3]] * wx[3];
+            }
+            v = rows[0] * wy[0] + rows[1] * wy[1] + rows[2] * wy[2] + rows[3] * wy[3];
+        }
+        out[i] = v;
+    }
+    // wave64 min / max, one atomic pair per wave
+    float lo = valid ? v : INFINITY, hi = valid ? v : -INFINITY;
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(reinterpret_cast<int*>(minmax), enc_ordered(lo));
+        atomicMax(reinterpret_cast<int*>(minmax) + 1, enc_ordered(hi));
+    }
+}
+
+__global__ __launch_bounds__(256) void word_post_kernel(float* out, int n, const float* minmax, int absolute,
+                                                        float threshold)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = out[i];
+    if (!absolute) {
+        const float lo = dec_ordered(reinterpret_cast<const int*>(minmax)[0]);
+        const float hi = dec_ordered(reinterpret_cast<const int*>(minmax)[1]);
+        v = (v - lo) / (hi - lo + 1e-8f);
+    }
+    if (threshold != 0.f) v = v > threshold ? 1.f : 0.f;      // `if threshold:` (heatmap.py:85)
+    out[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-callable launchers (called from daam_api.hip)
+// ---------------------------------------------------------------------------------------
+template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
+hipError_t launch_tap_generic(const TapLaunch& L, int in_dtype, int acc_dtype, int max_d, hipStream_t stream,
+                              int* grid_out, int* lds_out)
+{
+    const size_t lds = (size_t)L.tokens * max_d * sizeof(float) + 2 * kTapParts * kTapPixels * sizeof(float);
+    const int grid = L.wgs_per_xcd * 8;
+    *grid_out = grid;
+    *lds_out = (int)lds;
+    hipError_t e;
+#define DAAM_LAUNCH(IN, ACC)                                                            \
+    do {                                                                                \
+        if ((e = allow_lds(tap_generic_kernel<IN, ACC>, lds)) != hipSuccess) return e;  \
+        hipLaunchKernelGGL((tap_generic_kernel<IN, ACC>), dim3(grid), dim3(256), lds, stream, L); \
+    } while (0)
+    if (in_dtype == 0 && acc_dtype == 0) DAAM_LAUNCH(__half, __half);
+    else if (in_dtype == 0 && acc_dtype == 1) DAAM_LAUNCH(__half, float);
+    else DAAM_LAUNCH(float, float);
+#undef DAAM_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_tap_probs(const ProbsLaunch& L, int in_dtype, int acc_dtype, hipStream_t stream, int* grid_out,
+                            int* lds_out)
+{
+    const size_t lds = (size_t)kTapPixels * L.tokens * (in_dtype == 0 ? 2 : 4);
+    const int grid = L.wgs_per_xcd * 8;
+    *grid_out = grid;
+    *lds_out = (int)lds;
+    if (in_dtype == 0 && acc_dtype == 0)
+        hipLaunchKernelGGL((tap_probs_kernel<__half, __half>), dim3(grid), dim3(256), lds, stream, L);
+    else if (in_dtype == 0 && acc_dtype == 1)
+        hipLaunchKernelGGL((tap_probs_kernel<__half, float>), dim3(grid), dim3(256), lds, stream, L);
+    else
+        hipLaunchKernelGGL((tap_probs_kernel<float, float>), dim3(grid), dim3(256), lds, stream, L);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const FinLaunch& L, int acc_dtype, hipStream_t stream, int* grid_out, int* lds_out)
+{
+    const size_t lds = sizeof(float) * ((size_t)L.out_side * L.out_side + (size_t)L.max_side * L.max_side +
+                                        (size_t)L.max_side * L.out_side);
+    *grid_out = L.tokens * L.n_chunks;
+    *lds_out = (int)lds;
+    hipError_t e;
+    if (acc_dtype == 0) {
+        if ((e = allow_lds(finalize_kernel<__half>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((finalize_kernel<__half>), dim3(L.tokens, L.n_chunks), dim3(256), lds, stream, L);
+    } else {
+        if ((e = allow_lds(finalize_kernel<float>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((finalize_kernel<float>), dim3(L.tokens, L.n_chunks), dim3(256), lds, stream, L);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_normalize(float* maps, int n_rows, int plane, hipStream_t stream)
+{
+    hipLaunchKernelGGL(normalize_kernel, dim3((plane + 255) / 256), dim3(256), 0, stream, maps, n_rows, plane);
+    return hipGetLastError();
+}
+
+hipError_t launch_word(const float* maps, int side, const int32_t* idx, int n_idx, float* word_map, float* out,
+                       int out_h, int out_w, int absolute, float threshold, float* workspace, hipStream_t stream)
+{
+    WordIdx w;
+    w.n = n_idx;
+    for (int i = 0; i < n_idx; ++i) w.idx[i] = idx[i];
+    const int plane = side * side;
+    hipLaunchKernelGGL(word_mean_kernel, dim3((plane + 255) / 256), dim3(256), 0, stream, maps, plane, w, word_map,
+                       workspace);
+    if (out) {
+        const int n = out_h * out_w;
+        hipLaunchKernelGGL(word_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, word_map, side, out,
+                           out_h, out_w, workspace);
+        if (!absolute || threshold != 0.f)
+            hipLaunchKernelGGL(word_post_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, workspace,
+                               absolute, threshold);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace daam

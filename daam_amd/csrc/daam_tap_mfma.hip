@@ -1,0 +1,282 @@
+// fp16 tap for gfx950: S^T = K Q^T on the matrix cores, softmax in registers, running sums
+// in registers across every step of the launch, one coalesced write-back per launch.
+//
+// Reference semantics (daam/trace.py:276-294, daam/heatmap.py:153-156, diffusers 0.21.2
+// Attention.get_attention_scores):
+//   logits = fp16( f32(q . k) * scale )            (baddbmm output dtype)
+//   probs  = fp16( softmax_f32(logits) )           (probs.to(dtype))
+//   acc    = acc + probs  in the accumulator dtype (fp16 add = f32 add + one RNE)
+//
+// Workgroup = 256 threads = 4 waves, one (layer, kept head, 128-pixel tile).  Wave w owns
+// pixels [32w, 32w+32).  "Swapped" product: A = K (tokens x d), B = Q^T (d x pixels) with
+// v_mfma_f32_32x32x16_f16, so a lane holds ONE pixel (column lane&31) and, over the three
+// 32-token row tiles, 40 of its 77 token logits; the row reduction of the softmax is 39 in-lane
+// ops + one exchange with lane^32.  The contraction index is split as (k-step ks, lane half
+// g, element e) <-> d index 16*ks + 8*g + e for both operands, i.e. every operand fetch is
+// one aligned 16-byte piece of a q / k row.
+//
+// K of the current step sits in LDS (rows padded by 16 B: stride 4*(2*KS+1) dwords, odd
+// multiple of 4 -> ds_read_b128 conflict-free), double-buffered; Q and the next step's K are
+// fetched global -> VGPR one step ahead.
+#include "daam_types.h"
+
+namespace daam {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int kTok = 77;               // context_size (trace.py:194); the only value the reference taps
+constexpr int kTokRows = 96;           // 3 MFMA row tiles
+constexpr int kMfmaPixels = 128;       // pixels per workgroup
+constexpr int kSlots = 40;             // token slots per lane: 16 + 16 + 8
+
+__device__ __forceinline__ int mfma_logical_block(int total_wgs, int wgs_per_xcd) {
+    const int b = blockIdx.x;
+    const int l = (b & 7) * wgs_per_xcd + (b >> 3);
+    return l < total_wgs ? l : -1;
+}
+
+__device__ __forceinline__ int mfma_find_layer(const TapLayer* layers, int n, int wg) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (layers[mid].wg_begin <= wg) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// token of slot i for lane half g:  C/D row = (reg&3) + 8*(reg>>2) + 4*g  (+32 per row tile)
+__device__ __forceinline__ constexpr int slot_token(int i, int g) {
+    const int mt = i >> 4, reg = i & 15;
+    return mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * g;
+}
+
+template <typename ACC_T> struct AccVec;
+template <> struct AccVec<_Float16> { static constexpr int kPerVec = 8; };
+template <> struct AccVec<float> { static constexpr int kPerVec = 4; };
+
+template <int KS, typename ACC_T>
+__global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
+{
+    constexpr int KROW = KS * 32 + 16;                        // bytes per K row in LDS
+    constexpr int KBUF = kTokRows * KROW;                     // bytes per K buffer
+    constexpr int KCH = (kTok * 2 * KS + 255) / 256;          // 16-B K pieces per thread per step
+    constexpr int VEC = AccVec<ACC_T>::kPerVec;
+    constexpr int PPR = kMfmaPixels / VEC;                    // 16-B pieces per staging row
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* kbuf = smem;                               // [2][KBUF]
+    ACC_T* stage = reinterpret_cast<ACC_T*>(smem + 2 * KBUF); // [kTok][kMfmaPixels]
+
+    const int wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
+    if (wg < 0) return;
+    TapLayer lay;
+    const TapPtr* ptrs;
+    if (L.layers) {
+        lay = L.layers[mfma_find_layer(L.layers, L.n_layers, wg)];
+        ptrs = L.ptrs + lay.ptr_begin;
+    } else {
+        lay = L.one;
+        ptrs = &L.one_ptr;
+    }
+    const int nch = lay.head_dim >> 3;                        // 16-B pieces per q / k row
+    const int rel = wg - lay.wg_begin;
+    const int kh = rel / lay.tiles_per_head;
+    const int p0 = (rel - kh * lay.tiles_per_head) * kMfmaPixels;
+    const int bh = lay.bh_first + kh;
+    const int b = bh / lay.heads, h = bh - b * lay.heads;
+    const int64_t q_off = b * lay.q_sb + h * lay.q_sh;
+    const int64_t k_off = b * lay.k_sb + h * lay.k_sh;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, g = lane >> 5;
+    const int my_pixel = min(p0 + wave * 32 + n, lay.hw - 1);  // clamped: out-of-range columns are never stored
+
+    // zero the K padding pieces (head_dim not a multiple of 16: piece 2*KS-1) once, both buffers
+    if (nch < 2 * KS) {
+        for (int r = tid; r < 2 * kTokRows; r += 256)
+            *reinterpret_cast<float4v*>(kbuf + (r / kTokRows) * KBUF + (r % kTokRows) * KROW + nch * 16) = float4v{0, 0, 0, 0};
+    }
+
+    // ---- running sums -> registers --------------------------------------------------------
+    ACC_T run[kSlots];
+    ACC_T* acc = reinterpret_cast<ACC_T*>(lay.acc) + (size_t)kh * kTok * lay.hw;
+    if (!lay.fresh) {
+        for (int piece = tid; piece < kTok * PPR; piece += 256) {
+            const int row = piece / PPR, col = (piece - row * PPR) * VEC;
+            if (p0 + col < lay.hw)
+                *reinterpret_cast<float4v*>(stage + row * kMfmaPixels + col) =
+                    *reinterpret_cast<const float4v*>(acc + (size_t)row * lay.hw + p0 + col);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) {
+            const int t = slot_token(i, g);
+            run[i] = t < kTok ? stage[t * kMfmaPixels + wave * 32 + n] : (ACC_T)0;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) run[i] = (ACC_T)0;
+    }
+
+    // ---- software pipeline: K(s+1) and Q(s+1) in flight while step s computes ----------------
+    float4v kreg[KCH];
+    half8 breg[KS];
+    auto issue_k = [&](int s) {
+        const _Float16* kp = reinterpret_cast<const _Float16*>(ptrs[s].k) + k_off;
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) {
+            const int c = tid + 256 * j;
+            const int t = c / nch, ch = c - t * nch;
+            if (t < kTok) kreg[j] = *reinterpret_cast<const float4v*>(kp + t * lay.k_st + ch * 8);
+        }
+    };
+    auto commit_k = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) {
+            const int c = tid + 256 * j;
+            const int t = c / nch, ch = c - t * nch;
+            if (t < kTok) *reinterpret_cast<float4v*>(kbuf + buf * KBUF + t * KROW + ch * 16) = kreg[j];
+        }
+    };
+    auto issue_q = [&](int s) {
+        const _Float16* qp = reinterpret_cast<const _Float16*>(ptrs[s].q) + q_off + (int64_t)my_pixel * lay.q_sp;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int ch = 2 * ks + g;
+            if (ch < nch) breg[ks] = *reinterpret_cast<const half8*>(qp + ch * 8);
+            else breg[ks] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+
+    issue_k(0);
+    issue_q(0);
+    commit_k(0);
+    __syncthreads();
+
+    for (int s = 0; s < lay.n_steps; ++s) {
+        const unsigned char* kb = kbuf + (s & 1) * KBUF;
+        half8 bcur[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bcur[ks] = breg[ks];
+        const bool more = s + 1 < lay.n_steps;
+        if (more) { issue_k(s + 1); issue_q(s + 1); }
+
+        floatx16 c0 = {0}, c1 = {0}, c2 = {0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int col = (2 * ks + g) * 16;
+            const half8 a0 = *reinterpret_cast<const half8*>(kb + (n) * KROW + col);
+            const half8 a1 = *reinterpret_cast<const half8*>(kb + (32 + n) * KROW + col);
+            const half8 a2 = *reinterpret_cast<const half8*>(kb + (64 + n) * KROW + col);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bcur[ks], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bcur[ks], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, bcur[ks], c2, 0, 0, 0);
+        }
+
+        // logits: alpha in f32, then the baddbmm output rounding (optional: upcast_attention)
+        float x[kSlots];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { x[i] = c0[i]; x[16 + i] = c1[i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[32 + i] = c2[i];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) {
+            float v = x[i] * lay.scale;
+            if (lay.round_logits) v = (float)(_Float16)v;
+            if (slot_token(i, 1) >= kTok && g == 1) v = -INFINITY;      // slots 37..39 of the upper half: tokens 77..79
+            x[i] = v;
+            m = fmaxf(m, v);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) {
+            x[i] = expf(x[i] - m);
+            sum += x[i];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) {
+            const _Float16 prob = (_Float16)(x[i] / sum);                // probs.to(dtype)
+            run[i] = run[i] + (ACC_T)prob;                               // heatmap.py:156
+        }
+
+        if (more) commit_k((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- write back: registers -> LDS [token][pixel] -> 16-byte row pieces -------------------
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) {
+        const int t = slot_token(i, g);
+        if (t < kTok) stage[t * kMfmaPixels + wave * 32 + n] = run[i];
+    }
+    __syncthreads();
+    for (int piece = tid; piece < kTok * PPR; piece += 256) {
+        const int row = piece / PPR, col = (piece - row * PPR) * VEC;
+        if (p0 + col < lay.hw)
+            *reinterpret_cast<float4v*>(acc + (size_t)row * lay.hw + p0 + col) =
+                *reinterpret_cast<const float4v*>(stage + row * kMfmaPixels + col);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb,
+                        int64_t q_sh, int64_t k_sb, int64_t k_sh)
+{
+    if (in_dtype != 0 || tokens != kTok) return false;
+    if (head_dim % 8 != 0 || head_dim < 8 || head_dim > 160) return false;
+    if (hw % 8 != 0) return false;
+    const int64_t s[] = {q_sp, k_st, q_sb, q_sh, k_sb, k_sh};
+    for (int64_t v : s)
+        if (v % 8 != 0) return false;                       // every row piece 16-byte aligned
+    return true;
+}
+
+int tap_mfma_tile_pixels() { return kMfmaPixels; }
+int tap_mfma_ksteps(int head_dim) { return (head_dim + 15) / 16; }
+
+template <int KS, typename ACC_T>
+static hipError_t launch_one(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out)
+{
+    const size_t lds = 2 * (size_t)kTokRows * (KS * 32 + 16) + (size_t)kTok * kMfmaPixels * sizeof(ACC_T);
+    *lds_out = lds;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_mfma_kernel<KS, ACC_T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((tap_mfma_kernel<KS, ACC_T>), dim3(grid), dim3(256), lds, stream, L);
+    return hipGetLastError();
+}
+
+// every layer of the launch has the same k-step count ceil(head_dim / 16) (host groups by it)
+hipError_t launch_tap_mfma(const TapLaunch& L, int acc_dtype, int max_d, hipStream_t stream, int* grid_out,
+                           int* lds_out)
+{
+    const int grid = L.wgs_per_xcd * 8;
+    *grid_out = grid;
+    size_t lds = 0;
+    hipError_t e = hipErrorInvalidValue;
+    const int ks = tap_mfma_ksteps(max_d);
+#define DAAM_CASE(K)                                                                   \
+    case K:                                                                            \
+        e = acc_dtype == 0 ? launch_one<K, _Float16>(L, stream, grid, &lds)            \
+                           : launch_one<K, float>(L, stream, grid, &lds);              \
+        break;
+    switch (ks) {
+        DAAM_CASE(1) DAAM_CASE(2) DAAM_CASE(3) DAAM_CASE(4) DAAM_CASE(5) DAAM_CASE(6) DAAM_CASE(7) DAAM_CASE(8)
+        DAAM_CASE(9) DAAM_CASE(10)
+        default: break;
+    }
+#undef DAAM_CASE
+    *lds_out = (int)lds;
+    return e;
+}
+
+}  // namespace daam

@@ -1,0 +1,79 @@
+// Device-visible tables shared by the host API (daam_api.hip) and the kernels.
+// gfx950 only; no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace daam {
+
+constexpr int kMaxTokens = 80;        // context_size is 77 (reference trace.py:194); padded tiles use 80 / 96
+constexpr int kTapPixels = 64;        // query positions per workgroup tile (generic kernel)
+constexpr int kTapParts = 4;          // token chunks per pixel (one per wave of the 256-thread block)
+constexpr int kTokPerPart = kMaxTokens / kTapParts;   // 20
+
+// One layer's share of a tap launch.  All steps recorded for the layer in this launch have
+// the same shape / strides (the host flushes otherwise).
+struct TapLayer {
+    void* acc;              // running sums [heads_kept, tokens, hw] (ctx acc dtype)
+    int32_t heads_kept;     // BH - BH/2   (trace.py:240)
+    int32_t bh_first;       // BH/2: first kept batch*heads index
+    int32_t heads;          // H, to split bh -> (b, h)
+    int32_t hw;
+    int32_t head_dim;
+    int32_t tiles_per_head; // ceil(hw / tile pixels)
+    int32_t wg_begin;       // first (logical) workgroup of this layer in the launch
+    int32_t n_steps;        // recorded steps of this layer in this launch
+    int32_t ptr_begin;      // ptrs[ptr_begin + s] = step s
+    int32_t round_logits;
+    float scale;
+    int32_t fresh;          // 1: running sums are known to be zero (first tap since reset): skip the read
+    int64_t q_sb, q_sh, q_sp;
+    int64_t k_sb, k_sh, k_st;
+};
+
+struct TapPtr {
+    const void* q;
+    const void* k;
+};
+
+// Kernel argument block.  `layers == nullptr` selects the by-value single-call form
+// (immediate daam_tap_qk: no table upload, one layer, one step).
+struct TapLaunch {
+    const TapLayer* layers;
+    const TapPtr* ptrs;
+    int32_t n_layers;
+    int32_t tokens;
+    int32_t total_wgs;      // logical workgroups (grid is rounded up to a multiple of 8 XCDs)
+    int32_t wgs_per_xcd;    // ceil(total_wgs / 8)
+    TapLayer one;
+    TapPtr one_ptr;
+};
+
+struct ProbsLaunch {        // daam_tap_probs
+    void* acc;
+    const void* probs;      // [BH, hw, tokens] contiguous
+    int32_t heads_kept, bh_first, hw, tokens, tiles_per_head, total_wgs, wgs_per_xcd;
+};
+
+// One selected (layer, head) key of a finalize launch.
+struct FinKey {
+    const void* base;       // plane of token 0: [tokens, side, side] follows
+    int32_t side;
+    int32_t tab;            // bicubic table index (-1: side == out_side, identity)
+};
+
+struct FinLaunch {
+    const FinKey* keys;
+    const int16_t* tab_idx; // [n_tabs][out_side][4] border-clamped tap indices
+    const float* tab_w;     // [n_tabs][out_side][4] weights (A = -0.75)
+    float* out;             // [tokens, out_side, out_side]
+    int32_t n_keys;
+    int32_t n_chunks;
+    int32_t tokens;
+    int32_t out_side;
+    float inv_n;
+    int32_t max_side;       // largest non-identity side among the keys (LDS carve-up)
+};
+
+}  // namespace daam

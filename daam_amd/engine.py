@@ -1,0 +1,299 @@
+"""Device-side state of one trace: the per-(layer, head) running sums and the native context.
+
+Python owns the memory (torch tensors, so ``all_heat_maps`` hands out zero-copy views and the
+caching allocator sees it); ``libdaam_hip.so`` does all arithmetic.  Mirrors what the
+reference keeps in ``RawHeatMapCollection`` (daam/heatmap.py:148-172) plus the bodies of
+``UNetCrossAttentionHooker.__call__`` between scores and bmm (daam/trace.py:285-294) and
+``compute_global_heat_map`` (daam/trace.py:103-130).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as nat
+
+Key = Tuple[int, int, int]   # (factor, layer, head) -- daam/heatmap.py:145
+
+
+class HeatMapEngine:
+    def __init__(self, n_layers: int, tokens: int = 77, out_side: int = 64, accumulate: str = 'exact',
+                 defer_steps: int = 0):
+        """``accumulate``: ``'exact'`` keeps the running sums in the pipeline dtype like the
+        reference (fp16 sums on an fp16 pipeline, heatmap.py:156); ``'float32'`` is the
+        accuracy mode.  ``defer_steps`` > 0 records Q/K pointers and taps ``defer_steps``
+        denoising steps of all layers in one launch."""
+        if accumulate not in ('exact', 'float32'):
+            raise ValueError("accumulate must be 'exact' or 'float32'")
+        self.lib = nat.load()
+        self.n_layers = int(n_layers)
+        self.tokens = int(tokens)
+        self.out_side = int(out_side)
+        self.accumulate = accumulate
+        self.defer_steps = int(defer_steps)
+        self.ctx: Optional[nat.c_void_p] = None
+        self.device: Optional[torch.device] = None
+        self.acc_dtype: Optional[torch.dtype] = None
+        self.acc: Dict[int, torch.Tensor] = {}           # layer -> [heads, tokens, side, side]
+        self.layer_info: Dict[int, Tuple[int, int, int]] = {}   # layer -> (factor, heads, side)
+        self.touched: List[int] = []                     # layers updated since clear(), first-update order
+        self._held: List[torch.Tensor] = []              # q / k kept alive until the flush
+        self._pending: Dict[int, int] = {}
+        self._qk_cache: Dict[int, tuple] = {}
+        self._touched_set = set()
+
+    # ---- lifetime --------------------------------------------------------------------------
+    def _require_device(self, t: torch.Tensor) -> None:
+        if t.device.type != 'cuda':
+            raise RuntimeError(
+                'daam_amd: heat-map extraction runs only on an MI355X (HIP device); got a tensor on '
+                f'{t.device}. There is no CPU fallback.')
+        if self.device is None:
+            self.device = t.device
+        elif self.device != t.device:
+            raise RuntimeError(f'daam_amd: trace is bound to {self.device}, got a tensor on {t.device}')
+
+    def _ensure_ctx(self, pipe_dtype: torch.dtype) -> None:
+        if self.ctx is not None:
+            return
+        if pipe_dtype not in (torch.float16, torch.float32):
+            raise RuntimeError(f'daam_amd: unsupported pipeline dtype {pipe_dtype} (fp16 / fp32 only)')
+        self.acc_dtype = torch.float32 if self.accumulate == 'float32' else pipe_dtype
+        ctx = nat.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.daam_ctx_create(self.n_layers, self.tokens, self.out_side,
+                                               nat.DAAM_F16 if self.acc_dtype == torch.float16 else nat.DAAM_F32,
+                                               nat.byref(ctx)))
+        self.ctx = ctx
+
+    def close(self) -> None:
+        if self.ctx is not None:
+            self.lib.daam_ctx_destroy(self.ctx)
+            self.ctx = None
+        self.acc.clear()
+        self.layer_info.clear()
+        self.touched.clear()
+        self._touched_set.clear()
+        self._qk_cache.clear()
+        self._held.clear()
+        self._pending.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _ensure_layer(self, layer: int, heads: int, side: int, factor: int) -> None:
+        info = self.layer_info.get(layer)
+        if info == (factor, heads, side):
+            return
+        if info is not None:
+            # the reference would simply start a new key set / fail on a shape mismatch in `+`
+            self.flush()
+        buf = torch.zeros(heads, self.tokens, side, side, dtype=self.acc_dtype, device=self.device)
+        nat.check(self.lib.daam_layer_configure(self.ctx, layer, heads, side, factor, buf.data_ptr()))
+        self.acc[layer] = buf
+        self.layer_info[layer] = (factor, heads, side)
+
+    def _touch(self, layer: int) -> None:
+        if layer not in self._touched_set:
+            self._touched_set.add(layer)
+            self.touched.append(layer)
+
+    # ---- RawHeatMapCollection.clear (heatmap.py:170-172) -----------------------------------------
+    def clear(self) -> None:
+        self._held.clear()
+        self._pending.clear()
+        self.touched.clear()
+        self._touched_set.clear()
+        if self.ctx is not None:
+            nat.check(self.lib.daam_reset(self.ctx, self.stream))
+
+    # ---- tap -------------------------------------------------------------------------------------
+    def tap_qk(self, layer: int, query: torch.Tensor, key: torch.Tensor, heads: int, scale: float,
+               factor: int, round_logits: bool = True) -> None:
+        """``query`` [B, hw, heads*d], ``key`` [B, tokens, heads*d] straight out of ``to_q`` /
+        ``to_k`` (trace.py:262,269); no ``head_to_batch_dim`` copy is made."""
+        c = self._qk_cache.get(layer)
+        if (c is None or c[0] != query.shape or c[1] != key.shape or c[2] is not query.dtype or c[3] != heads
+                or c[4] != scale or c[5] != round_logits or c[6] != factor or key.dtype is not query.dtype):
+            c = self._prepare_qk(layer, query, key, heads, scale, factor, round_logits)
+        if not query.is_contiguous():
+            query = query.contiguous()
+        if not key.is_contiguous():
+            key = key.contiguous()
+        if self.defer_steps > 0:
+            if self._pending.get(layer, 0) >= self.defer_steps:
+                self.flush()
+            rc = self.lib.daam_tap_qk_enqueue(self.ctx, layer, query.data_ptr(), key.data_ptr(), c[7])
+            if rc == nat.E_STATE:           # shape / dtype changed inside the batch
+                self.flush()
+                rc = self.lib.daam_tap_qk_enqueue(self.ctx, layer, query.data_ptr(), key.data_ptr(), c[7])
+            if rc:
+                nat.check(rc)
+            self._held.append(query)
+            self._held.append(key)
+            self._pending[layer] = self._pending.get(layer, 0) + 1
+        else:
+            rc = self.lib.daam_tap_qk(self.ctx, layer, query.data_ptr(), key.data_ptr(), c[7], self.stream)
+            if rc:
+                nat.check(rc)
+        if layer not in self._touched_set:
+            self._touch(layer)
+
+    def _prepare_qk(self, layer, query, key, heads, scale, factor, round_logits):
+        """Slow path of ``tap_qk``: validate, (re)configure the layer, build the call descriptor."""
+        self._require_device(query)
+        self._ensure_ctx(query.dtype)
+        if query.dtype != key.dtype:
+            raise RuntimeError('daam_amd: query / key dtype mismatch')
+        if query.dtype == torch.float32 and self.acc_dtype == torch.float16:
+            raise RuntimeError('daam_amd: fp32 activations on a trace whose running sums are fp16')
+        b, hw, c = query.shape
+        tokens = key.shape[1]
+        d = c // heads
+        side = int(math.sqrt(hw))
+        bh = b * heads
+        self._ensure_layer(layer, bh - bh // 2, side, factor)
+        desc = nat.QKDesc(
+            in_dtype=nat.DAAM_F16 if query.dtype == torch.float16 else nat.DAAM_F32,
+            batch=b, heads=heads, hw=hw, tokens=tokens, head_dim=d, round_logits=1 if round_logits else 0,
+            scale=float(scale),
+            q_stride_b=hw * c, q_stride_h=d, q_stride_p=c,
+            k_stride_b=tokens * c, k_stride_h=d, k_stride_t=c)
+        entry = (query.shape, key.shape, query.dtype, heads, scale, round_logits, factor, nat.byref(desc), desc)
+        self._qk_cache[layer] = entry
+        return entry
+
+    def flush(self) -> None:
+        """Run every recorded (deferred) tap; the held Q/K references are dropped afterwards
+        (stream order keeps their memory valid until the kernel has consumed it)."""
+        if self.ctx is None or not self._pending:
+            return
+        nat.check(self.lib.daam_tap_flush(self.ctx, self.stream))
+        self._held.clear()
+        self._pending.clear()
+
+    def tap_probs(self, layer: int, probs: torch.Tensor, factor: int) -> None:
+        """``probs`` [B*H, hw, tokens] as returned by ``get_attention_scores`` (trace.py:276)."""
+        self._require_device(probs)
+        self._ensure_ctx(probs.dtype)
+        self.flush()
+        probs = probs if probs.is_contiguous() else probs.contiguous()
+        bh, hw, tokens = probs.shape
+        self._ensure_layer(layer, bh - bh // 2, int(math.sqrt(hw)), factor)
+        nat.check(self.lib.daam_tap_probs(self.ctx, layer, probs.data_ptr(),
+                                          nat.DAAM_F16 if probs.dtype == torch.float16 else nat.DAAM_F32,
+                                          bh, hw, tokens, self.stream))
+        self._touch(layer)
+
+    def add_map(self, factor: int, layer: int, head: int, heat_map: torch.Tensor) -> None:
+        """``RawHeatMapCollection.update`` called by hand (heatmap.py:153-156): rare, done with a
+        torch add on the layer's buffer."""
+        self._require_device(heat_map)
+        self._ensure_ctx(heat_map.dtype)
+        self.flush()
+        t, h, w = heat_map.shape
+        if layer not in self.layer_info:
+            raise RuntimeError('daam_amd: update() on a layer that was never tapped is not supported')
+        self.acc[layer][head] += heat_map.to(self.acc_dtype)
+        self._touch(layer)
+
+    # ---- views -----------------------------------------------------------------------------------
+    def keys(self) -> List[Key]:
+        out: List[Key] = []
+        for layer in self.touched:
+            factor, heads, _ = self.layer_info[layer]
+            out += [(factor, layer, h) for h in range(heads)]
+        return out
+
+    def items(self) -> Iterator[Tuple[Key, torch.Tensor]]:
+        self.flush()
+        for layer in list(self.touched):
+            factor, heads, _ = self.layer_info[layer]
+            buf = self.acc[layer]
+            for h in range(heads):
+                yield (factor, layer, h), buf[h]
+
+    # ---- finalize ---------------------------------------------------------------------------------
+    def global_heat_map(self, factors: Optional[Sequence[int]] = None, head_idx: Optional[int] = None,
+                        layer_idx: Optional[int] = None) -> torch.Tensor:
+        """trace.py:103-126: returns ``[tokens, x, x]`` fp32 on the device."""
+        fset = {0, 1, 2, 4, 8, 16, 32, 64} if factors is None else set(factors)
+        if self.ctx is None or not self.touched:
+            raise LookupError('no heat maps')
+        self.flush()
+        total = ctypes.c_int()
+        nat.check(self.lib.daam_key_offset(self.ctx, 0, None, ctypes.byref(total)))
+        mask = (ctypes.c_uint8 * total.value)()
+        n = 0
+        for layer in self.touched:
+            factor, heads, _ = self.layer_info[layer]
+            if factor not in fset or (layer_idx is not None and layer_idx != layer):
+                continue
+            off = ctypes.c_int()
+            nat.check(self.lib.daam_key_offset(self.ctx, layer, ctypes.byref(off), None))
+            for h in range(heads):
+                if head_idx is None or head_idx == h:
+                    mask[off.value + h] = 1
+                    n += 1
+        if n == 0:
+            raise LookupError('no heat maps')
+        out = torch.empty(self.tokens, self.out_side, self.out_side, dtype=torch.float32, device=self.device)
+        nat.check(self.lib.daam_finalize(self.ctx, mask, out.data_ptr(), self.stream))
+        return out
+
+    def normalize_(self, maps: torch.Tensor) -> torch.Tensor:
+        """trace.py:129-130, in place on ``maps`` [n_rows, x, x] (contiguous fp32)."""
+        nat.check(self.lib.daam_epilogue_normalize(maps.data_ptr(), maps.shape[0], maps.shape[-1], self.stream))
+        return maps
+
+
+def word_heat_map(maps: torch.Tensor, idxs: Sequence[int]) -> torch.Tensor:
+    """heatmap.py:121-123: mean of the planes ``idxs`` of ``maps`` [rows, s, s] -> [s, s]."""
+    lib = nat.load()
+    _check_maps(maps)
+    side = maps.shape[-1]
+    idx = (ctypes.c_int32 * len(idxs))(*[int(i) for i in idxs])
+    for i in idxs:
+        if not 0 <= int(i) < maps.shape[0]:
+            raise IndexError(f'index {i} is out of bounds for dimension 0 with size {maps.shape[0]}')
+    word = torch.empty(side, side, dtype=torch.float32, device=maps.device)
+    ws = torch.empty(2, dtype=torch.float32, device=maps.device)
+    nat.check(lib.daam_word_heat_map(maps.data_ptr(), side, idx, len(idxs), word.data_ptr(), None, 0, 0, 1, 0.0,
+                                     ws.data_ptr(), torch.cuda.current_stream(maps.device).cuda_stream))
+    return word
+
+
+def expand_word_map(word: torch.Tensor, out_h: int, out_w: int, absolute: bool = False,
+                    threshold: Optional[float] = None) -> torch.Tensor:
+    """heatmap.py:77-93 up to (not including) the ``.cpu()``: bicubic to ``out_h x out_w``,
+    min-max normalise unless ``absolute``, optional threshold."""
+    lib = nat.load()
+    if word.device.type != 'cuda' or word.dtype != torch.float32 or word.dim() != 2 or word.shape[0] != word.shape[1]:
+        raise RuntimeError('daam_amd: expand_as needs a square fp32 word map on the HIP device')
+    word = word.contiguous()
+    side = word.shape[-1]
+    out = torch.empty(out_h, out_w, dtype=torch.float32, device=word.device)
+    tmp = torch.empty(side, side, dtype=torch.float32, device=word.device)
+    ws = torch.empty(2, dtype=torch.float32, device=word.device)
+    idx = (ctypes.c_int32 * 1)(0)
+    nat.check(lib.daam_word_heat_map(word.data_ptr(), side, idx, 1, tmp.data_ptr(), out.data_ptr(), out_h, out_w,
+                                     1 if absolute else 0, float(threshold) if threshold else 0.0, ws.data_ptr(),
+                                     torch.cuda.current_stream(word.device).cuda_stream))
+    return out
+
+
+def _check_maps(maps: torch.Tensor) -> None:
+    if maps.device.type != 'cuda':
+        raise RuntimeError('daam_amd: heat maps must live on the HIP device (no CPU fallback)')
+    if maps.dtype != torch.float32 or not maps.is_contiguous() or maps.dim() != 3 or maps.shape[1] != maps.shape[2]:
+        raise RuntimeError('daam_amd: heat maps must be a contiguous fp32 [rows, s, s] tensor')

@@ -1,0 +1,145 @@
+/* daam_hip.h -- C ABI of libdaam_hip.so: the MI355X (gfx950) heat-map extraction path.
+ *
+ * This is the drop-in boundary for the ONE hot path of castorini/daam v0.2.0
+ * (paths below are relative to the reference checkout):
+ *
+ *   tap       = what UNetCrossAttentionHooker.__call__ does between get_attention_scores and
+ *               bmm (daam/trace.py:276-294): softmax(scale*Q K^T) -> keep the conditional
+ *               half of the batch*heads dim -> [heads, tokens, h, w] -> per-(layer, head)
+ *               running sum (RawHeatMapCollection.update, daam/heatmap.py:153-156).
+ *   finalize  = DiffusionHeatMapHooker.compute_global_heat_map (daam/trace.py:103-130):
+ *               key filter -> bicubic resize to x*x -> clamp(min=0) -> mean over keys
+ *               (-> token crop is a view; optional per-pixel normalisation = epilogue).
+ *   word maps = GlobalHeatMap.compute_word_heat_map + WordHeatMap.expand_as
+ *               (daam/heatmap.py:121-123, 77-93)  [SURVEY.md section 8f row f1].
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch types.
+ *   - every `const void*` / `void*` data pointer is a DEVICE pointer owned by the caller
+ *     unless the parameter is documented as "host".
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every call only
+ *     ENQUEUES work on that stream and returns; nothing synchronises the host except
+ *     daam_ctx_destroy and the (rare) wrap-around of the internal upload ring.
+ *   - return value: 0 = ok; > 0 = a hipError_t from the HIP runtime; < 0 = DAAM_E_* below.
+ *     daam_last_error() gives the message of the last failure on the calling thread.
+ *   - not thread-safe per context (the reference is not re-entrant either: it serialises
+ *     generation with a lock, daam/run/demo.py:69,88).
+ */
+#ifndef DAAM_HIP_H
+#define DAAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAAM_ABI_VERSION 1
+
+/* element types of activations (q, k, probs) and of the running sums */
+#define DAAM_F16 0
+#define DAAM_F32 1
+
+/* DAAM_E_* */
+#define DAAM_E_INVALID   (-1)   /* bad argument / shape / dtype */
+#define DAAM_E_STATE     (-2)   /* call not valid in the current state (e.g. layer not configured) */
+#define DAAM_E_NOMAPS    (-3)   /* finalize selected zero keys (reference: RuntimeError, trace.py:118-124) */
+#define DAAM_E_UNSUPPORTED (-4)
+
+typedef struct DaamCtx DaamCtx;
+
+/* How one cross-attention call lays out its projected query / key.
+ * Logical q is [batch, heads, hw, head_dim], k is [batch, heads, tokens, head_dim]; head_dim is
+ * contiguous (stride 1), the other strides are given in ELEMENTS so that both the
+ * head_to_batch_dim layout [B*H, S, d] (trace.py:272-273) and the raw to_q/to_k output
+ * [B, S, H*d] (trace.py:262,269) can be tapped without a copy.
+ * The reference keeps batch*heads indices [BH/2, BH) (trace.py:240): with classifier-free
+ * guidance (batch 2) that is the conditional prompt, all heads. */
+typedef struct DaamQKDesc {
+    int32_t in_dtype;        /* DAAM_F16 | DAAM_F32: dtype of q and k (the pipeline dtype) */
+    int32_t batch;           /* B */
+    int32_t heads;           /* H */
+    int32_t hw;              /* query positions = h*w, square (trace.py:233) */
+    int32_t tokens;          /* key positions; only ctx->tokens (77) is tapped (trace.py:289) */
+    int32_t head_dim;        /* d */
+    int32_t round_logits;    /* 1: round scale*q.k to in_dtype before softmax (baddbmm output
+                                dtype in diffusers get_attention_scores); 0: upcast_attention */
+    float   scale;           /* attn.scale = head_dim ** -0.5 */
+    int64_t q_stride_b, q_stride_h, q_stride_p;
+    int64_t k_stride_b, k_stride_h, k_stride_t;
+} DaamQKDesc;
+
+/* ---- context ---------------------------------------------------------------------------
+ * One context per trace object per device (reference: one RawHeatMapCollection per
+ * DiffusionHeatMapHooker, trace.py:31).  tokens = context_size (77, trace.py:194);
+ * out_side = int(sqrt(latent_hw)) (64, or 96 for 768-px SD-2.x; trace.py:32-33,109);
+ * acc_dtype = dtype of the running sums: DAAM_F16 reproduces the reference's fp16 sums on an
+ * fp16 pipeline bit-for-bit in the add (heatmap.py:156), DAAM_F32 is the accuracy mode. */
+int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, DaamCtx** out);
+int daam_ctx_destroy(DaamCtx* ctx);
+
+/* Declare layer `layer` (= position in UNetCrossAttentionLocator.locate order, trace.py:45,50):
+ * `heads` = kept batch*heads entries (BH - BH/2), `side` = sqrt(hw), `factor` =
+ * int(sqrt(latent_hw // hw)) (trace.py:285).  `acc` = caller-owned zero-initialised device
+ * buffer [heads, tokens, side, side] of acc_dtype, or NULL to let the library allocate it. */
+int daam_layer_configure(DaamCtx* ctx, int layer, int heads, int side, int factor, void* acc);
+int daam_layer_acc(DaamCtx* ctx, int layer, void** acc, size_t* bytes);
+
+/* RawHeatMapCollection.clear (heatmap.py:170-172; called from check_inputs, trace.py:179):
+ * zero every running sum and drop any un-flushed deferred taps. */
+int daam_reset(DaamCtx* ctx, void* stream);
+
+/* ---- tap -------------------------------------------------------------------------------
+ * daam_tap_qk: one hooked cross-attention call, immediate: one kernel launch that
+ * recomputes the conditional-half probabilities from q,k and adds them to the layer's sums.
+ * daam_tap_qk_enqueue + daam_tap_flush: deferred form.  enqueue only records pointers (the
+ * caller keeps q,k alive until the flush has been enqueued on `stream` and stream order
+ * protects them); flush runs ALL recorded calls - every layer, every recorded step - as one
+ * launch, adding the steps of a layer in the order they were recorded (so fp16 sums round
+ * exactly like the reference's step-by-step adds) while reading and writing each running
+ * sum once per flush instead of once per step.
+ * daam_tap_probs: same accumulate from materialised probabilities [B*H, hw, tokens]
+ * (the save_heads / load_heads path, trace.py:279-282, and any processor that already
+ * holds attention_probs); bit-exact with the reference in the add. */
+int daam_tap_qk(DaamCtx* ctx, int layer, const void* q, const void* k, const DaamQKDesc* d, void* stream);
+int daam_tap_qk_enqueue(DaamCtx* ctx, int layer, const void* q, const void* k, const DaamQKDesc* d);
+int daam_tap_pending(DaamCtx* ctx, int* n_calls, int* max_steps);
+int daam_tap_flush(DaamCtx* ctx, void* stream);
+int daam_tap_probs(DaamCtx* ctx, int layer, const void* probs, int in_dtype, int batch_heads,
+                   int hw, int tokens, void* stream);
+
+/* ---- finalize ---------------------------------------------------------------------------
+ * compute_global_heat_map (trace.py:103-126) over the keys selected by `key_mask`:
+ * HOST array, one byte per (layer, head) in layer-major order over configured layers'
+ * `heads` (offset of layer l = sum of heads of layers < l, see daam_key_offset), non-zero =
+ * selected.  NULL selects every key.  Writes out[tokens, out_side, out_side] fp32 =
+ * mean over selected keys of clamp(bicubic(sum_plane), 0).  `out` is overwritten. */
+int daam_key_offset(DaamCtx* ctx, int layer, int* offset, int* total);
+int daam_finalize(DaamCtx* ctx, const uint8_t* key_mask, float* out, void* stream);
+
+/* trace.py:129-130: maps[:n_rows] / (maps[1:n_rows-1].sum(0) + 1e-6), in place on the first
+ * n_rows planes of `maps` [*, side, side] fp32. */
+int daam_epilogue_normalize(float* maps, int n_rows, int side, void* stream);
+
+/* ---- word maps (next row f1) -------------------------------------------------------------
+ * heatmap.py:121-123 + 77-93: mean of the planes `idx[0..n_idx)` (HOST int array) of
+ * maps[*, side, side] -> bicubic to out_h x out_w -> (absolute ? id : min-max normalise with
+ * eps 1e-8) -> (threshold > 0 ? (x > threshold) : x).  word_map[side*side] (optional, may be
+ * NULL) receives the un-expanded mean plane; `out` [out_h, out_w] fp32;
+ * `workspace` >= 2 floats of device scratch for the min/max. */
+int daam_word_heat_map(const float* maps, int side, const int32_t* idx, int n_idx, float* word_map,
+                       float* out, int out_h, int out_w, int absolute, float threshold,
+                       float* workspace, void* stream);
+
+/* ---- misc -------------------------------------------------------------------------------- */
+int daam_abi_version(void);
+const char* daam_last_error(void);
+/* per-kernel launch statistics of the last tap / finalize launch (for bench.py):
+ * grid size and dynamic LDS bytes; 0 if nothing launched yet. */
+int daam_last_launch(DaamCtx* ctx, int which /*0 tap,1 finalize*/, int* grid, int* block, int* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAAM_HIP_H */

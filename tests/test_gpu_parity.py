@@ -1,0 +1,326 @@
+"""GPU parity: the HIP path (through the C ABI, libdaam_hip.so) against the numpy oracle and the
+golden vectors produced by executing the unmodified reference.  Run with ``-m gpu`` on an
+MI355X.  Tolerances are stated next to each comparison:
+
+  * fp32 pipeline, fp32 sums ........ <= 2e-6 * max|ref|  (summation order only)
+  * fp16 pipeline, fp16 sums ('exact') vs the literal fp16 reference:
+        raw running sums ............ <= 1 ulp of the sum (a logit straddling an fp16 rounding
+                                      boundary moves one probability by one ulp)
+        global heat maps ............ <= 1e-3 max-abs (BASELINE.json north_star); observed ~1e-4
+  * probabilities path (tap='probs') . bit-exact running sums (same adds, same order)
+"""
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_CASES, golden_pipe, load_golden
+from oracle import heatmap_oracle as ho
+from oracle.make_golden import SAMPLE_TOKENS
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def _engine(n_layers=4, **kw):
+    from daam_amd.engine import HeatMapEngine
+    return HeatMapEngine(n_layers, tokens=77, out_side=kw.pop('out_side', 64), **kw)
+
+
+def _qk(rng, batch, heads, hw, d, dtype, sos_gain=3.0):
+    q = rng.standard_normal((batch, hw, heads * d)).astype(np.float32)
+    k = rng.standard_normal((batch, 77, heads * d)).astype(np.float32)
+    k[:, 0, :] *= sos_gain
+    return q.astype(dtype), k.astype(dtype)
+
+
+def _to_bh(x, heads):
+    b, s, c = x.shape
+    d = c // heads
+    return np.ascontiguousarray(x.reshape(b, s, heads, d).transpose(0, 2, 1, 3)).reshape(b * heads, s, d)
+
+
+def _oracle_steps(qs, ks, heads, scale, pipe_dtype, acc_dtype):
+    raw = ho.RawMaps(acc_dtype)
+    for q, k in zip(qs, ks):
+        ho.tap(raw, 0, _to_bh(q, heads), _to_bh(k, heads), scale, latent_hw=q.shape[1], pipe_dtype=pipe_dtype)
+    return np.stack([v for _, v in raw])          # [kept heads, 77, h, w]
+
+
+SHAPES = [
+    # (batch, heads, side, d)
+    (2, 2, 8, 8),          # one partial 128-pixel tile, one k-step with a zero-padded piece
+    (2, 3, 16, 40),        # SD-v1.5 head dim 40 (3 k-steps, last half padded)
+    (2, 2, 32, 64),        # SDXL head dim
+    (2, 1, 24, 80),        # hw = 576: partial tile (4.5 tiles of 128)
+    (2, 1, 16, 160),       # SD-v1.5 deepest level
+    (1, 4, 16, 64),        # no CFG: keeps heads 2..3 (trace.py:240)
+    (4, 2, 16, 16),        # num_images_per_prompt=2 under CFG: keeps batch 2..3
+    (2, 2, 10, 12),        # d % 8 != 0 and hw % 8 != 0 -> generic kernel
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('mode', ['f16_exact', 'f16_f32acc', 'f32'])
+@pytest.mark.parametrize('defer', [0, 3])
+def test_tap_qk_vs_oracle(shape, mode, defer):
+    batch, heads, side, d = shape
+    hw = side * side
+    steps = 4
+    rng = np.random.default_rng(sum(shape) * 7 + len(mode))
+    np_dt = np.float32 if mode == 'f32' else np.float16
+    acc_np = np.float16 if mode == 'f16_exact' else np.float32
+    scale = d ** -0.5
+    qs, ks = zip(*[_qk(rng, batch, heads, hw, d, np_dt) for _ in range(steps)])
+    want = _oracle_steps(qs, ks, heads, scale, np_dt, acc_np).astype(np.float64)
+
+    eng = _engine(accumulate='exact' if mode != 'f16_f32acc' else 'float32', defer_steps=defer)
+    for q, k in zip(qs, ks):
+        eng.tap_qk(0, torch.from_numpy(q).to(DEV), torch.from_numpy(k).to(DEV), heads, scale, factor=1)
+    got = np.stack([v.float().cpu().numpy() for _, v in eng.items()]).astype(np.float64)
+    assert got.shape == want.shape
+    if mode == 'f32':
+        tol = 2e-6 * max(1.0, np.abs(want).max())
+    elif mode == 'f16_exact':
+        tol = 2.0 ** -10 * max(1.0, want.max())          # 1 ulp of the largest fp16 running sum
+    else:
+        tol = steps * 2.0 ** -11                          # one flipped fp16 probability ulp per step
+    err = np.abs(got - want).max()
+    assert err <= tol, f'{shape} {mode} defer={defer}: max-abs {err} > {tol}'
+    # every step's probabilities sum to one over the tokens
+    np.testing.assert_allclose(got.sum(1), steps, atol=steps * 77 * 2.0 ** -11)
+    eng.close()
+
+
+def test_generic_and_mfma_agree(monkeypatch):
+    """The baseline (any-shape) kernel and the MFMA kernel implement the same rounding points."""
+    rng = np.random.default_rng(7)
+    q, k = _qk(rng, 2, 2, 1024, 64, np.float16)
+    outs = []
+    for force in ('1', '0'):
+        monkeypatch.setenv('DAAM_FORCE_GENERIC', force)
+        eng = _engine()
+        eng.tap_qk(0, torch.from_numpy(q).to(DEV), torch.from_numpy(k).to(DEV), 2, 0.125, factor=2)
+        outs.append(np.stack([v.float().cpu().numpy() for _, v in eng.items()]))
+        eng.close()
+    # different f32 summation order in the dot product: a few logits straddle an fp16 boundary
+    diff = np.abs(outs[0] - outs[1])
+    assert diff.max() <= 2.0 ** -10
+    assert (diff > 0).mean() < 0.02
+
+
+def test_deferred_equals_immediate_bits():
+    """Deferring steps changes the launch structure, not one bit of the result."""
+    rng = np.random.default_rng(11)
+    steps = 7
+    data = [_qk(rng, 2, 2, 256, 64, np.float16) for _ in range(steps)]
+    res = []
+    for defer in (0, 1, 3, 50):
+        eng = _engine(defer_steps=defer)
+        for q, k in data:
+            eng.tap_qk(1, torch.from_numpy(q).to(DEV), torch.from_numpy(k).to(DEV), 2, 0.125, factor=4)
+        res.append(torch.stack([v for _, v in eng.items()]).cpu())
+        eng.close()
+    for r in res[1:]:
+        assert torch.equal(res[0], r)
+
+
+@pytest.mark.parametrize('dt', ['float16', 'float32'])
+def test_tap_probs_bit_exact(dt):
+    rng = np.random.default_rng(3)
+    np_dt = np.dtype(dt)
+    heads, hw, steps = 3, 144, 5                          # hw = 12*12: not a multiple of the 64-pixel tile
+    raw = ho.RawMaps(np_dt)
+    eng = _engine()
+    for s in range(steps):
+        q, k = _qk(rng, 2, heads, hw, 16, np_dt)
+        probs = ho.attention_probs(_to_bh(q, heads), _to_bh(k, heads), 0.25, np_dt)
+        ho.tap(raw, 2, None, None, 0.25, latent_hw=4096, pipe_dtype=np_dt, probs=probs)
+        eng.tap_probs(2, torch.from_numpy(probs).to(DEV), factor=5)
+    want = np.stack([v for _, v in raw])
+    got = torch.stack([v for _, v in eng.items()]).cpu().numpy()
+    assert got.dtype == want.dtype
+    np.testing.assert_array_equal(got, want)
+    assert [k for k, _ in eng.items()] == [(5, 2, h) for h in range(heads)]
+    eng.close()
+
+
+@pytest.mark.parametrize('sides', [(64,), (32,), (16, 32, 64), (128, 64), (8,), (24, 48)])
+@pytest.mark.parametrize('acc', ['float16', 'float32'])
+def test_finalize_vs_oracle(sides, acc):
+    """bicubic (A=-0.75, border-clamped taps) -> clamp -> mean over keys, incl. the x0.5
+    down-sample of SDXL-2048 (128 -> 64) and the 96x96 output of 768-px models."""
+    rng = np.random.default_rng(len(sides) * 31 + sides[0])
+    out_side = 96 if 24 in sides else 64
+    heads = 2
+    eng = _engine(n_layers=len(sides), out_side=out_side, accumulate='exact' if acc == 'float16' else 'float32')
+    raw = []
+    for layer, side in enumerate(sides):
+        # signed planes so that the clamp matters; feed them through the probs path (adds to zero)
+        planes = (rng.standard_normal((2 * heads, side * side, 77)) * 3).astype(acc)
+        eng.tap_probs(layer, torch.from_numpy(planes).to(DEV), factor=out_side // side if side <= out_side else 0)
+        kept = ho.unravel(planes)
+        factor = out_side // side if side <= out_side else 0
+        raw += [((factor, layer, h), kept[h]) for h in range(heads)]
+    lat = out_side * out_side
+    for kw in [dict(), dict(head_idx=1), dict(layer_idx=len(sides) - 1), dict(factors=[raw[0][0][0]])]:
+        want = ho.global_heat_map(raw, lat, **kw)
+        got = eng.global_heat_map(**kw).cpu().numpy()
+        tol = 3e-6 * max(1.0, np.abs(want).max())
+        np.testing.assert_allclose(got, want, rtol=0, atol=tol, err_msg=f'{sides} {kw}')
+    with pytest.raises(LookupError):
+        eng.global_heat_map(head_idx=99)
+    eng.close()
+
+
+def test_normalize_and_word_maps():
+    rng = np.random.default_rng(5)
+    maps = np.abs(rng.standard_normal((9, 64, 64))).astype(np.float32)
+    from daam_amd import engine as E
+    eng = _engine()
+    t = torch.from_numpy(maps.copy()).to(DEV)
+    eng._require_device(t)
+    got = eng.normalize_(t).cpu().numpy()
+    want = maps / (maps[1:-1].sum(0, keepdims=True) + np.float32(1e-6))
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7)
+    gm = torch.from_numpy(maps).to(DEV)
+    wm = E.word_heat_map(gm, [2, 3, 5])
+    np.testing.assert_allclose(wm.cpu().numpy(), ho.word_heat_map(maps, [2, 3, 5]), rtol=1e-6, atol=1e-7)
+    for size in (64, 128, 512):
+        for kw in (dict(), dict(absolute=True), dict(threshold=0.4)):
+            got = E.expand_word_map(wm, size, size, **kw).cpu().numpy()
+            want = ho.expand_as(wm.cpu().numpy(), size, **kw)
+            if 'threshold' in kw:
+                assert (got != want).mean() < 1e-4          # values within 1e-6 of the threshold may flip
+            else:
+                np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# end to end through the reference's API against the golden vectors of the unmodified reference
+# ---------------------------------------------------------------------------------------------
+def _global_tol(meta):
+    return 2e-6 if meta['dtype'] == 'float32' else 1e-3       # north_star: <= 1e-3 max-abs in fp16
+
+
+@pytest.mark.parametrize('tap,defer', [('qk', 0), ('qk', 2), ('qk', 50), ('probs', 0)])
+def test_trace_api_matches_reference_golden(golden_case, tap, defer):
+    import daam_amd
+    name, z, meta = golden_case
+    pipe = golden_pipe(meta, device=DEV)
+    with daam_amd.trace(pipe, tap=tap, defer_steps=defer) as tc:
+        out = pipe(meta['prompt'], num_inference_steps=meta['steps'], callback=tc.time_callback)
+        items = list(tc.all_heat_maps)
+        keys = np.asarray([k for k, _ in items], dtype=np.int32)
+        np.testing.assert_array_equal(keys, z['keys'])              # same keys, same first-update order
+        assert str(items[0][1].dtype) == str(z['raw_dtype'])
+        sums = np.asarray([float(v.double().sum()) for _, v in items])
+        np.testing.assert_allclose(sums, z['key_sum'], rtol=2e-4 if meta['dtype'] == 'float16' else 1e-5)
+        for sid in z['raw_sample_ids']:
+            got = items[int(sid)][1][SAMPLE_TOKENS].float().cpu().numpy()
+            want = z[f'raw_{int(sid)}']
+            tol = 2e-6 if meta['dtype'] == 'float32' else 2.0 ** -10 * max(1.0, float(want.max()))
+            np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+        for vn, kw in json.loads(str(z['variants'])).items():
+            got = tc.compute_global_heat_map(**kw).heat_maps
+            want = z[f'global_{vn}']
+            assert got.dtype == torch.float32 and tuple(got.shape) == want.shape
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0,
+                                       atol=_global_tol(meta) * max(1.0, float(np.abs(want).max())),
+                                       err_msg=f'{name}:{vn}')
+        ghm = tc.compute_global_heat_map()
+        whm = ghm.compute_word_heat_map(str(z['word']))
+        np.testing.assert_allclose(whm.heatmap.cpu().numpy(), z['word_map'], rtol=0, atol=_global_tol(meta))
+
+        class _Img:
+            size = (128, 128)
+        # min-max normalisation divides by the range of the word map: scale the tolerance with it
+        span = float(z['word_map'].max() - z['word_map'].min())
+        np.testing.assert_allclose(whm.expand_as(_Img()).numpy(), z['word_expand_128'], rtol=0,
+                                   atol=max(2e-5, 4 * _global_tol(meta) / max(span, 1e-6)) if meta['dtype'] == 'float16'
+                                   else 5e-5)
+        np.testing.assert_allclose(whm.expand_as(_Img(), absolute=True).numpy(), z['word_expand_128_abs'], rtol=0,
+                                   atol=max(2e-5, _global_tol(meta)))
+        assert tc.layer_names == json.loads(str(z['layer_names']))
+        assert tc.last_prompt == str(z['last_prompt'])
+        assert str(tc.last_image) == str(z['last_image'])
+        assert int(tc.time_idx) == int(z['time_idx'])
+    assert out.images
+
+
+def test_trace_errors_and_reset():
+    import daam_amd
+    z, meta = load_golden('sd15_f16')
+    pipe = golden_pipe(meta, device=DEV)
+    tc = daam_amd.trace(pipe)
+    with pytest.raises(RuntimeError, match='Module is not hooked'):
+        tc.unhook()
+    with tc:
+        with pytest.raises(RuntimeError, match='Already hooked module'):
+            tc.hook()
+        with pytest.raises(RuntimeError, match='Did you forget'):
+            tc.compute_global_heat_map()
+        with pytest.raises(ValueError, match='Only single prompt'):
+            pipe(['a', 'b'])
+        pipe('a dog', num_inference_steps=2)
+        a = tc.compute_global_heat_map().heat_maps.clone()
+        with pytest.raises(RuntimeError, match='given parameters'):
+            tc.compute_global_heat_map(layer_idx=999)
+        pipe('a dog', num_inference_steps=2)                         # check_inputs clears the sums (trace.py:179)
+        b = tc.compute_global_heat_map().heat_maps
+        assert torch.allclose(a, b, rtol=0, atol=1e-6)                # f32 atomics: order may differ
+        with pytest.raises(ValueError, match='not found in prompt'):
+            tc.compute_global_heat_map().compute_word_heat_map('cat')
+    assert type(pipe.unet.execution_order()[0].module.processor).__name__ == 'DefaultProcessor'
+
+
+def test_cpu_tensors_fail_loudly():
+    import daam_amd
+    z, meta = load_golden('sd15_f32')
+    pipe = golden_pipe(meta, device='cpu')
+    with daam_amd.trace(pipe) as tc:
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            pipe('a dog', num_inference_steps=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size (BASELINE.json configs) properties that do not need the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('heads,side,d', [(10, 64, 64), (20, 32, 64), (8, 64, 40), (5, 128, 64)])
+def test_full_size_layer_properties(heads, side, d):
+    """SDXL / SD-v1.5 / SDXL-2048 layer shapes: (i) the token sums of the running sums equal the
+    number of steps at every pixel; (ii) deferral does not change a bit; (iii) an all-equal-keys
+    input gives the uniform map 1/77; (iv) finalize of one key at the output resolution is a
+    clamp-copy of the sums."""
+    hw = side * side
+    g = torch.Generator(device='cpu').manual_seed(heads * 1000 + side)
+    steps = 3
+    qs = [torch.randn(2, hw, heads * d, generator=g).half().to(DEV) for _ in range(steps)]
+    k = torch.randn(2, 77, heads * d, generator=g).half()
+    k[:, 0] *= 3
+    k = k.to(DEV)
+    res = []
+    for defer in (0, 8):
+        eng = _engine(accumulate='float32', defer_steps=defer)
+        for q in qs:
+            eng.tap_qk(0, q, k, heads, d ** -0.5, factor=max(0, 64 // side))
+        acc = torch.stack([v for _, v in eng.items()])
+        res.append(acc.clone())
+        tok_sum = acc.sum(1)
+        assert (tok_sum - steps).abs().max().item() <= steps * 77 * 2.0 ** -12
+        if side == 64:
+            gm = eng.global_heat_map(head_idx=1)
+            assert torch.allclose(gm, acc[1].clamp(min=0), atol=1e-6)
+        eng.close()
+    assert torch.equal(res[0], res[1])
+    eng = _engine()
+    kc = k.clone()
+    kc[:] = kc[:, :1]                                            # all keys identical -> uniform attention
+    eng.tap_qk(0, qs[0], kc, heads, d ** -0.5, factor=1)
+    acc = torch.stack([v for _, v in eng.items()]).float()
+    assert (acc - float(np.float16(1.0 / 77))).abs().max().item() == 0.0
+    eng.close()
