@@ -23,6 +23,9 @@ int tap_mfma_tile_pixels();
 int tap_mfma_ksteps(int head_dim);
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
+hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
+hipError_t launch_finalize_up(const FinLaunch&, int side, int, hipStream_t, int*);
+bool finalize_up_supported(int side, int out_side);
 hipError_t launch_normalize(float*, int, int, hipStream_t);
 hipError_t launch_word(const float*, int, const int32_t*, int, float*, float*, int, int, int, float, float*,
                        hipStream_t);
@@ -525,8 +528,9 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
 {
     if (!c || !out) return fail(DAAM_E_INVALID, "NULL argument");
     if (!c->pending.empty()) return fail(DAAM_E_STATE, "finalize with deferred taps pending: flush first");
-    std::vector<FinKey> keys;
-    int pos = 0, max_side = 0;
+    // classes: 0 = same size (clamp + mean), 1 = x2 (32 -> 64), 2 = x4 (16 -> 64), 3 = general kernel
+    std::vector<FinKey> keys[4];
+    int pos = 0, max_side = 0, total = 0;
     for (int i = 0; i < c->max_layers; ++i) {
         const Layer& l = c->layers[i];
         if (!l.configured) continue;
@@ -536,34 +540,65 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             k.base = static_cast<const char*>(l.acc) + (size_t)h * c->tokens * l.hw * acc_elem(c->acc_dtype);
             k.side = l.side;
             k.tab = l.tab;
-            if (l.tab >= 0) max_side = std::max(max_side, l.side);
-            keys.push_back(k);
+            int cls = 3;
+            if (!c->force_generic) {
+                if (l.tab < 0 && (l.hw % 8) == 0) cls = 0;
+                else if (l.tab >= 0 && finalize_up_supported(l.side, c->out_side)) cls = l.side == 32 ? 1 : 2;
+            }
+            if (cls == 3 && l.tab >= 0) max_side = std::max(max_side, l.side);
+            keys[cls].push_back(k);
+            ++total;
         }
     }
-    if (keys.empty()) return fail(DAAM_E_NOMAPS, "no heat maps selected");
+    if (total == 0) return fail(DAAM_E_NOMAPS, "no heat maps selected");
     if (max_side > 128) return fail(DAAM_E_UNSUPPORTED, "map side %d > 128 not supported by finalize", max_side);
     hipStream_t s = (hipStream_t)stream;
     const size_t plane = (size_t)c->out_side * c->out_side;
     HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * c->tokens * plane, s));
     size_t off = 0;
-    const size_t bytes = keys.size() * sizeof(FinKey);
+    const size_t bytes = (size_t)total * sizeof(FinKey);
     HIP_TRY(c->ring.alloc(bytes, &off));
-    memcpy(c->ring.host + off, keys.data(), bytes);
+    {
+        FinKey* dst = reinterpret_cast<FinKey*>(c->ring.host + off);
+        for (auto& v : keys) { memcpy(dst, v.data(), v.size() * sizeof(FinKey)); dst += v.size(); }
+    }
     HIP_TRY(c->ring.commit(off, bytes, s));
-    FinLaunch L;
-    L.keys = reinterpret_cast<const FinKey*>(c->ring.dev + off);
-    L.tab_idx = c->d_tab_idx;
-    L.tab_w = c->d_tab_w;
-    L.out = out;
-    L.n_keys = (int)keys.size();
-    L.n_chunks = std::max(1, std::min(L.n_keys, 32));
-    L.tokens = c->tokens;
-    L.out_side = c->out_side;
-    L.inv_n = 1.0f / (float)L.n_keys;
-    L.max_side = max_side;
+    const FinKey* dev = reinterpret_cast<const FinKey*>(c->ring.dev + off);
     c->last_block[1] = 256;
-    hipError_t e = launch_finalize(L, c->acc_dtype, s, &c->last_grid[1], &c->last_lds[1]);
-    if (e != hipSuccess) return fail((int)e, "finalize launch: %s", hipGetErrorString(e));
+    c->last_grid[1] = 0;
+    c->last_lds[1] = 0;
+    static const int env_chunks = getenv("DAAM_FIN_CHUNKS") ? atoi(getenv("DAAM_FIN_CHUNKS")) : 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int n = (int)keys[cls].size();
+        if (n == 0) { continue; }
+        FinLaunch L;
+        L.keys = dev;
+        dev += n;
+        L.tab_idx = c->d_tab_idx;
+        L.tab_w = c->d_tab_w;
+        L.out = out;
+        L.n_keys = n;
+        L.tokens = c->tokens;
+        L.out_side = c->out_side;
+        L.inv_n = 1.0f / (float)total;
+        L.max_side = max_side;
+        int grid = 0, lds = 0;
+        hipError_t e;
+        if (cls == 0) {
+            L.n_chunks = std::max(1, std::min(n, env_chunks ? env_chunks : 8));
+            e = launch_finalize_same(L, c->acc_dtype, s, &grid);
+        } else if (cls == 3) {
+            L.n_chunks = std::max(1, std::min(n, 32));
+            e = launch_finalize(L, c->acc_dtype, s, &grid, &lds);
+        } else {
+            const int want = env_chunks ? env_chunks : 16;
+            L.n_chunks = std::max(1, std::min((n + 3) / 4, want));
+            e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, s, &grid);
+        }
+        if (e != hipSuccess) return fail((int)e, "finalize launch (class %d): %s", cls, hipGetErrorString(e));
+        c->last_grid[1] += grid;
+        c->last_lds[1] = std::max(c->last_lds[1], lds);
+    }
     HIP_TRY(c->ring.release(s));
     return 0;
 }

@@ -47,6 +47,20 @@ __device__ __forceinline__ int mfma_find_layer(const TapLayer* layers, int n, in
     return lo;
 }
 
+constexpr float kMasked = -1.0e30f;    // logit of the padding tokens: exp() underflows to exactly 0
+
+// e^d for d <= 0 to ~1 ulp: 2^(d*log2e) on v_exp_f32 with the rounding error of the product
+// (and the low part of log2e) folded back in:  2^t * (1 + err * ln2).
+__device__ __forceinline__ float exp_nonpos(float d) {
+    const float L = 1.44269502162933349609375f;       // log2(e) rounded to f32
+    const float Llo = 1.92596303e-08f;                // log2(e) - L
+    const float t = d * L;
+    float err = __builtin_fmaf(d, L, -t);
+    err = __builtin_fmaf(d, Llo, err);
+    const float r = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(r, err * 0.693147182f, r);
+}
+
 // token of slot i for lane half g:  C/D row = (reg&3) + 8*(reg>>2) + 4*g  (+32 per row tile)
 __device__ __forceinline__ constexpr int slot_token(int i, int g) {
     const int mt = i >> 4, reg = i & 15;
@@ -177,32 +191,38 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
             c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, bcur[ks], c2, 0, 0, 0);
         }
 
-        // logits: alpha in f32, then the baddbmm output rounding (optional: upcast_attention)
+        // logits: alpha in f32, then the baddbmm output rounding (skipped for upcast_attention)
         float x[kSlots];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { x[i] = c0[i]; x[16 + i] = c1[i]; }
+        for (int i = 0; i < 16; ++i) { x[i] = c0[i] * lay.scale; x[16 + i] = c1[i] * lay.scale; }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[32 + i] = c2[i];
-        float m = -INFINITY;
+        for (int i = 0; i < 8; ++i) x[32 + i] = c2[i] * lay.scale;
+        if (lay.round_logits) {
 #pragma unroll
-        for (int i = 0; i < kSlots; ++i) {
-            float v = x[i] * lay.scale;
-            if (lay.round_logits) v = (float)(_Float16)v;
-            if (slot_token(i, 1) >= kTok && g == 1) v = -INFINITY;      // slots 37..39 of the upper half: tokens 77..79
-            x[i] = v;
-            m = fmaxf(m, v);
+            for (int i = 0; i < kSlots; ++i) x[i] = (float)(_Float16)x[i];
         }
+        if (g == 1) { x[37] = kMasked; x[38] = kMasked; x[39] = kMasked; }   // tokens 77..79 of the upper lane half
+        float m0 = x[0], m1 = x[1], m2 = x[2], m3 = x[3];
+#pragma unroll
+        for (int i = 4; i < kSlots; i += 4) {
+            m0 = fmaxf(m0, x[i]); m1 = fmaxf(m1, x[i + 1]); m2 = fmaxf(m2, x[i + 2]); m3 = fmaxf(m3, x[i + 3]);
+        }
+        float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float sum = 0.f;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-        for (int i = 0; i < kSlots; ++i) {
-            x[i] = expf(x[i] - m);
-            sum += x[i];
+        for (int i = 0; i < kSlots; i += 4) {
+            x[i] = exp_nonpos(x[i] - m);         s0 += x[i];
+            x[i + 1] = exp_nonpos(x[i + 1] - m); s1 += x[i + 1];
+            x[i + 2] = exp_nonpos(x[i + 2] - m); s2 += x[i + 2];
+            x[i + 3] = exp_nonpos(x[i + 3] - m); s3 += x[i + 3];
         }
+        float sum = (s0 + s1) + (s2 + s3);
         sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
 #pragma unroll
         for (int i = 0; i < kSlots; ++i) {
-            const _Float16 prob = (_Float16)(x[i] / sum);                // probs.to(dtype)
+            const _Float16 prob = (_Float16)(x[i] * inv);                // probs.to(dtype)
             run[i] = run[i] + (ACC_T)prob;                               // heatmap.py:156
         }
 
