@@ -19,7 +19,7 @@ E_INVALID, E_STATE, E_NOMAPS, E_UNSUPPORTED = -1, -2, -3, -4
 # every symbol include/daam_hip.h declares (tests check the library exports exactly these)
 EXPORTS = (
     'daam_abi_version', 'daam_last_error', 'daam_ctx_create', 'daam_ctx_destroy', 'daam_layer_configure',
-    'daam_layer_acc', 'daam_reset', 'daam_tap_qk', 'daam_tap_qk_enqueue', 'daam_tap_pending', 'daam_tap_flush',
+    'daam_layer_acc', 'daam_reset', 'daam_tap_qk', 'daam_tap_qk_enqueue', 'daam_tap_qk_enqueue_many', 'daam_tap_pending', 'daam_tap_flush',
     'daam_tap_probs', 'daam_key_offset', 'daam_finalize', 'daam_epilogue_normalize', 'daam_word_heat_map',
     'daam_last_launch',
 )
@@ -62,6 +62,7 @@ def load() -> ctypes.CDLL:
     lib.daam_reset.argtypes = [c_void_p, c_void_p]
     lib.daam_tap_qk.argtypes = [c_void_p, c_int, c_void_p, c_void_p, POINTER(QKDesc), c_void_p]
     lib.daam_tap_qk_enqueue.argtypes = [c_void_p, c_int, c_void_p, c_void_p, POINTER(QKDesc)]
+    lib.daam_tap_qk_enqueue_many.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.daam_tap_pending.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
     lib.daam_tap_flush.argtypes = [c_void_p, c_void_p]
     lib.daam_tap_probs.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]

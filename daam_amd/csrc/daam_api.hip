@@ -21,6 +21,7 @@ bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t 
                         int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh);
 int tap_mfma_tile_pixels();
 int tap_mfma_ksteps(int head_dim);
+int tap_mfma_max_steps();
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
 hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
@@ -154,6 +155,9 @@ struct DaamCtx {
     float* d_tab_w = nullptr;
     std::vector<int> tab_sides;
     std::vector<Pending> pending;
+    std::vector<int> pending_count;   // per layer: recorded steps
+    std::vector<int> pending_last;    // per layer: index of its newest entry in `pending`
+    void drop_pending() { pending.clear(); pending_count.clear(); pending_last.clear(); }
     int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
     int force_generic = 0;
 };
@@ -287,7 +291,7 @@ int daam_layer_acc(DaamCtx* c, int layer, void** acc, size_t* bytes)
 int daam_reset(DaamCtx* c, void* stream)
 {
     if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
-    c->pending.clear();
+    c->drop_pending();
     for (auto& l : c->layers)
         if (l.configured) {
             HIP_TRY(hipMemsetAsync(l.acc, 0, l.bytes, (hipStream_t)stream));
@@ -371,22 +375,45 @@ int daam_tap_qk_enqueue(DaamCtx* c, int layer, const void* q, const void* k, con
 {
     int rc = check_qk(c, layer, q, k, d);
     if (rc) return rc;
-    if (!c->pending.empty()) {
-        if (c->pending.front().d.in_dtype != d->in_dtype)
-            return fail(DAAM_E_STATE, "mixed activation dtypes in one deferred batch: flush first");
+    if (!c->pending.empty() && c->pending.front().d.in_dtype != d->in_dtype)
+        return fail(DAAM_E_STATE, "mixed activation dtypes in one deferred batch: flush first");
+    if (c->pending_count.size() != (size_t)c->max_layers) {
+        c->pending_count.assign(c->max_layers, 0);
+        c->pending_last.assign(c->max_layers, -1);
+    }
+    if (c->pending_count[layer] > 0) {
         // every recorded step of a layer must share shape and strides
-        for (auto it = c->pending.rbegin(); it != c->pending.rend(); ++it) {
-            if (it->layer != layer) continue;
-            const DaamQKDesc& o = it->d;
-            if (o.batch != d->batch || o.heads != d->heads || o.head_dim != d->head_dim ||
-                o.round_logits != d->round_logits || o.scale != d->scale || o.q_stride_b != d->q_stride_b ||
-                o.q_stride_h != d->q_stride_h || o.q_stride_p != d->q_stride_p || o.k_stride_b != d->k_stride_b ||
-                o.k_stride_h != d->k_stride_h || o.k_stride_t != d->k_stride_t)
-                return fail(DAAM_E_STATE, "layer %d changed shape inside a deferred batch: flush first", layer);
-            break;
+        const DaamQKDesc& o = c->pending[c->pending_last[layer]].d;
+        if (o.batch != d->batch || o.heads != d->heads || o.head_dim != d->head_dim ||
+            o.round_logits != d->round_logits || o.scale != d->scale || o.q_stride_b != d->q_stride_b ||
+            o.q_stride_h != d->q_stride_h || o.q_stride_p != d->q_stride_p || o.k_stride_b != d->k_stride_b ||
+            o.k_stride_h != d->k_stride_h || o.k_stride_t != d->k_stride_t)
+            return fail(DAAM_E_STATE, "layer %d changed shape inside a deferred batch: flush first", layer);
+        if (c->pending_count[layer] >= tap_mfma_max_steps())
+            return fail(DAAM_E_STATE, "layer %d already has %d un-flushed steps: flush first", layer,
+                        c->pending_count[layer]);
+    }
+    c->pending_last[layer] = (int)c->pending.size();
+    ++c->pending_count[layer];
+    c->pending.push_back({layer, q, k, *d});
+    return 0;
+}
+
+int daam_tap_qk_enqueue_many(DaamCtx* c, int n, const int32_t* layers, const void* const* q, const void* const* k,
+                             const DaamQKDesc* const* descs)
+{
+    if (!c || n < 0 || (n > 0 && (!layers || !q || !k || !descs))) return fail(DAAM_E_INVALID, "NULL argument");
+    const size_t before = c->pending.size();
+    for (int i = 0; i < n; ++i) {
+        int rc = daam_tap_qk_enqueue(c, layers[i], q[i], k[i], descs[i]);
+        if (rc) {
+            // all or nothing: rebuild the per-layer bookkeeping for the surviving prefix
+            std::vector<Pending> keep(c->pending.begin(), c->pending.begin() + before);
+            c->drop_pending();
+            for (auto& p : keep) (void)daam_tap_qk_enqueue(c, p.layer, p.q, p.k, &p.d);
+            return rc;
         }
     }
-    c->pending.push_back({layer, q, k, *d});
     return 0;
 }
 
@@ -476,7 +503,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     }
     c->last_grid[0] = grid_total;
     c->last_block[0] = 256;
-    c->pending.clear();
+    c->drop_pending();
     return rc;
 }
 

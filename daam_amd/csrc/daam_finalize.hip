@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
 #pragma unroll
         for (int j = 0; j < PL; ++j) {
             const int piece = lane + 64 * j;
-            if (piece < NP) pre[j] = *reinterpret_cast<const typename P::Piece*>(src + piece * P::kPerPiece);
+            if (piece < NP) pre[j] = *as_global<typename P::Piece>(src + piece * P::kPerPiece);
         }
     };
     if (kidx < L.n_keys) fetch(kidx);
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void finalize_same_kernel(const FinLaunch L)
 #pragma unroll 4
     for (; kidx < L.n_keys; kidx += stride) {
         const ACC_T* src = reinterpret_cast<const ACC_T*>(L.keys[kidx].base) + (size_t)tok * plane + off;
-        P::clamp_add(*reinterpret_cast<const typename P::Piece*>(src), a);
+        const typename P::Piece piece = *as_global<typename P::Piece>(src);
+        P::clamp_add(piece, a);
     }
     float* out = L.out + (size_t)tok * plane + off;
 #pragma unroll

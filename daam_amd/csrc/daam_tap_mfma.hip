@@ -38,13 +38,24 @@ __device__ __forceinline__ int mfma_logical_block(int total_wgs, int wgs_per_xcd
     return l < total_wgs ? l : -1;
 }
 
-__device__ __forceinline__ int mfma_find_layer(const TapLayer* layers, int n, int wg) {
+__device__ __forceinline__ int mfma_find_layer(const DAAM_GLOBAL TapLayer* layers, int n, int wg) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (layers[mid].wg_begin <= wg) lo = mid; else hi = mid - 1;
     }
     return lo;
+}
+
+constexpr int kMaxStepsPerLaunch = 256;   // per-layer step pointers staged in LDS (4 KiB)
+
+__device__ __forceinline__ void load_layer(const DAAM_GLOBAL TapLayer* g, TapLayer* out) {
+    out->acc = g->acc; out->heads_kept = g->heads_kept; out->bh_first = g->bh_first; out->heads = g->heads;
+    out->hw = g->hw; out->head_dim = g->head_dim; out->tiles_per_head = g->tiles_per_head;
+    out->wg_begin = g->wg_begin; out->n_steps = g->n_steps; out->ptr_begin = g->ptr_begin;
+    out->round_logits = g->round_logits; out->scale = g->scale; out->fresh = g->fresh;
+    out->q_sb = g->q_sb; out->q_sh = g->q_sh; out->q_sp = g->q_sp;
+    out->k_sb = g->k_sb; out->k_sh = g->k_sh; out->k_st = g->k_st;
 }
 
 constexpr float kMasked = -1.0e30f;    // logit of the padding tokens: exp() underflows to exactly 0
@@ -87,14 +98,29 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
     const int wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
     if (wg < 0) return;
     TapLayer lay;
-    const TapPtr* ptrs;
-    if (L.layers) {
-        lay = L.layers[mfma_find_layer(L.layers, L.n_layers, wg)];
-        ptrs = L.ptrs + lay.ptr_begin;
+    const bool table = L.layers != nullptr;
+    if (table) {
+        const DAAM_GLOBAL TapLayer* gl = as_global<TapLayer>(L.layers);
+        load_layer(gl + mfma_find_layer(gl, L.n_layers, wg), &lay);
     } else {
         lay = L.one;
-        ptrs = &L.one_ptr;
     }
+    // per-step q / k base pointers -> LDS once, so the step loop never waits on a dependent
+    // global load (table fetch -> address -> data) on its critical path
+    const void** sptr = reinterpret_cast<const void**>(smem + 2 * KBUF + kTok * kMfmaPixels * sizeof(ACC_T));
+    if (table) {
+        const DAAM_GLOBAL TapPtr* ptrs = as_global<TapPtr>(L.ptrs) + lay.ptr_begin;
+        for (int i = threadIdx.x; i < lay.n_steps; i += 256) {
+            sptr[2 * i] = ptrs[i].q;
+            sptr[2 * i + 1] = ptrs[i].k;
+        }
+    } else if (threadIdx.x == 0) {
+        sptr[0] = L.one_ptr.q;
+        sptr[1] = L.one_ptr.k;
+    }
+    __syncthreads();
+    auto step_q = [&](int s) -> const void* { return sptr[2 * s]; };
+    auto step_k = [&](int s) -> const void* { return sptr[2 * s + 1]; };
     const int nch = lay.head_dim >> 3;                        // 16-B pieces per q / k row
     const int rel = wg - lay.wg_begin;
     const int kh = rel / lay.tiles_per_head;
@@ -123,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
             const int row = piece / PPR, col = (piece - row * PPR) * VEC;
             if (p0 + col < lay.hw)
                 *reinterpret_cast<float4v*>(stage + row * kMfmaPixels + col) =
-                    *reinterpret_cast<const float4v*>(acc + (size_t)row * lay.hw + p0 + col);
+                    *as_global<float4v>(acc + (size_t)row * lay.hw + p0 + col);
         }
         __syncthreads();
 #pragma unroll
@@ -137,48 +163,42 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
     }
 
     // ---- software pipeline: K(s+1) and Q(s+1) in flight while step s computes ----------------
-    float4v kreg[KCH];
-    half8 breg[KS];
-    auto issue_k = [&](int s) {
-        const _Float16* kp = reinterpret_cast<const _Float16*>(ptrs[s].k) + k_off;
+    // Two operand register sets used in ping-pong (loop unrolled by two, no register copies) and
+    // branch-free prefetch (addresses clamped instead of predicated) so that the compiler's
+    // s_waitcnt vmcnt(N) can leave the newest prefetch outstanding behind the MFMA / softmax.
+    const int n_steps = lay.n_steps;
+    // per-thread K piece coordinates (fixed for the whole launch)
+    int k_src[KCH], k_dst[KCH];
 #pragma unroll
-        for (int j = 0; j < KCH; ++j) {
-            const int c = tid + 256 * j;
-            const int t = c / nch, ch = c - t * nch;
-            if (t < kTok) kreg[j] = *reinterpret_cast<const float4v*>(kp + t * lay.k_st + ch * 8);
-        }
-    };
-    auto commit_k = [&](int buf) {
+    for (int j = 0; j < KCH; ++j) {
+        const int c = tid + 256 * j;
+        const int t = c / nch, ch = c - t * nch;
+        const int tc = min(t, kTok - 1);
+        k_src[j] = tc * (int)lay.k_st + ch * 8;                 // elements (clamped duplicate row when t >= 77)
+        k_dst[j] = t < kTok ? t * KROW + ch * 16 : -1;
+    }
+    const int64_t q_row = q_off + (int64_t)my_pixel * lay.q_sp;
+    auto issue_k = [&](int s, float4v (&kr)[KCH]) {
+        const _Float16* kp = reinterpret_cast<const _Float16*>(step_k(s)) + k_off;
 #pragma unroll
-        for (int j = 0; j < KCH; ++j) {
-            const int c = tid + 256 * j;
-            const int t = c / nch, ch = c - t * nch;
-            if (t < kTok) *reinterpret_cast<float4v*>(kbuf + buf * KBUF + t * KROW + ch * 16) = kreg[j];
-        }
+        for (int j = 0; j < KCH; ++j) kr[j] = *as_global<float4v>(kp + k_src[j]);
     };
-    auto issue_q = [&](int s) {
-        const _Float16* qp = reinterpret_cast<const _Float16*>(ptrs[s].q) + q_off + (int64_t)my_pixel * lay.q_sp;
+    auto commit_k = [&](int buf, const float4v (&kr)[KCH]) {
+#pragma unroll
+        for (int j = 0; j < KCH; ++j)
+            if (k_dst[j] >= 0) *reinterpret_cast<float4v*>(kbuf + buf * KBUF + k_dst[j]) = kr[j];
+    };
+    auto issue_q = [&](int s, half8 (&bq)[KS]) {
+        const _Float16* qp = reinterpret_cast<const _Float16*>(step_q(s)) + q_row;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int ch = 2 * ks + g;
-            if (ch < nch) breg[ks] = *reinterpret_cast<const half8*>(qp + ch * 8);
-            else breg[ks] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            const int ch = min(2 * ks + g, nch - 1);
+            bq[ks] = *as_global<half8>(qp + ch * 8);
         }
+        if (nch < 2 * KS && g == 1) bq[KS - 1] = half8{0, 0, 0, 0, 0, 0, 0, 0};   // zero-padded last piece
     };
-
-    issue_k(0);
-    issue_q(0);
-    commit_k(0);
-    __syncthreads();
-
-    for (int s = 0; s < lay.n_steps; ++s) {
-        const unsigned char* kb = kbuf + (s & 1) * KBUF;
-        half8 bcur[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bcur[ks] = breg[ks];
-        const bool more = s + 1 < lay.n_steps;
-        if (more) { issue_k(s + 1); issue_q(s + 1); }
-
+    auto compute = [&](const half8 (&bq)[KS], int buf) {
+        const unsigned char* kb = kbuf + buf * KBUF;
         floatx16 c0 = {0}, c1 = {0}, c2 = {0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -186,11 +206,10 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
             const half8 a0 = *reinterpret_cast<const half8*>(kb + (n) * KROW + col);
             const half8 a1 = *reinterpret_cast<const half8*>(kb + (32 + n) * KROW + col);
             const half8 a2 = *reinterpret_cast<const half8*>(kb + (64 + n) * KROW + col);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bcur[ks], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bcur[ks], c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, bcur[ks], c2, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[ks], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[ks], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, bq[ks], c2, 0, 0, 0);
         }
-
         // logits: alpha in f32, then the baddbmm output rounding (skipped for upcast_attention)
         float x[kSlots];
 #pragma unroll
@@ -225,10 +244,31 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
             const _Float16 prob = (_Float16)(x[i] * inv);                // probs.to(dtype)
             run[i] = run[i] + (ACC_T)prob;                               // heatmap.py:156
         }
+    };
 
-        if (more) commit_k((s + 1) & 1);
+    float4v kreg[KCH];
+    half8 bA[KS], bB[KS];
+    issue_k(0, kreg);
+    issue_q(0, bA);
+    commit_k(0, kreg);
+    __syncthreads();
+    int s = 0;
+    for (; s + 1 < n_steps; s += 2) {
+        // step s (operands bA, K buffer 0); prefetch step s+1
+        issue_k(s + 1, kreg);
+        issue_q(s + 1, bB);
+        compute(bA, 0);
+        commit_k(1, kreg);
+        __syncthreads();
+        // step s+1 (operands bB, K buffer 1); prefetch step s+2 (clamped: the tail re-fetches the last step)
+        const int nx = min(s + 2, n_steps - 1);
+        issue_k(nx, kreg);
+        issue_q(nx, bA);
+        compute(bB, 1);
+        commit_k(0, kreg);
         __syncthreads();
     }
+    if (s < n_steps) compute(bA, 0);                                     // odd step count: last step
 
     // ---- write back: registers -> LDS [token][pixel] -> 16-byte row pieces -------------------
 #pragma unroll
@@ -240,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
     for (int piece = tid; piece < kTok * PPR; piece += 256) {
         const int row = piece / PPR, col = (piece - row * PPR) * VEC;
         if (p0 + col < lay.hw)
-            *reinterpret_cast<float4v*>(acc + (size_t)row * lay.hw + p0 + col) =
+            *as_global_rw<float4v>(acc + (size_t)row * lay.hw + p0 + col) =
                 *reinterpret_cast<const float4v*>(stage + row * kMfmaPixels + col);
     }
 }
@@ -259,12 +299,14 @@ bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t 
 }
 
 int tap_mfma_tile_pixels() { return kMfmaPixels; }
+int tap_mfma_max_steps() { return kMaxStepsPerLaunch; }
 int tap_mfma_ksteps(int head_dim) { return (head_dim + 15) / 16; }
 
 template <int KS, typename ACC_T>
 static hipError_t launch_one(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out)
 {
-    const size_t lds = 2 * (size_t)kTokRows * (KS * 32 + 16) + (size_t)kTok * kMfmaPixels * sizeof(ACC_T);
+    const size_t lds = 2 * (size_t)kTokRows * (KS * 32 + 16) + (size_t)kTok * kMfmaPixels * sizeof(ACC_T) +
+                       (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);
     *lds_out = lds;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_mfma_kernel<KS, ACC_T>),

@@ -7,6 +7,17 @@
 
 namespace daam {
 
+// Pointers that arrive through a device table are "generic" to the compiler, which then emits
+// flat_load (counted on lgkmcnt as well as vmcnt, so every LDS wait also waits for HBM).
+// Everything the tables hold is global memory: say so.
+#define DAAM_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ const DAAM_GLOBAL T* as_global(const void* p) {
+    return (const DAAM_GLOBAL T*)(p);
+}
+template <typename T> __device__ __forceinline__ DAAM_GLOBAL T* as_global_rw(void* p) {
+    return (DAAM_GLOBAL T*)(p);
+}
+
 constexpr int kMaxTokens = 80;        // context_size is 77 (reference trace.py:194); padded tiles use 80 / 96
 constexpr int kTapPixels = 64;        // query positions per workgroup tile (generic kernel)
 constexpr int kTapParts = 4;          // token chunks per pixel (one per wave of the 256-thread block)

@@ -12,6 +12,7 @@ import ctypes
 import math
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import _native as nat
@@ -40,7 +41,11 @@ class HeatMapEngine:
         self.acc: Dict[int, torch.Tensor] = {}           # layer -> [heads, tokens, side, side]
         self.layer_info: Dict[int, Tuple[int, int, int]] = {}   # layer -> (factor, heads, side)
         self.touched: List[int] = []                     # layers updated since clear(), first-update order
-        self._held: List[torch.Tensor] = []              # q / k kept alive until the flush
+        # deferred taps: recorded per call (the tensors are kept alive until the flush)
+        self._rec_layer: List[int] = []
+        self._rec_q: List[torch.Tensor] = []
+        self._rec_k: List[torch.Tensor] = []
+        self._rec_desc: List[int] = []
         self._pending: Dict[int, int] = {}
         self._qk_cache: Dict[int, tuple] = {}
         self._touched_set = set()
@@ -78,8 +83,7 @@ class HeatMapEngine:
         self.touched.clear()
         self._touched_set.clear()
         self._qk_cache.clear()
-        self._held.clear()
-        self._pending.clear()
+        self._drop_recorded()
 
     def __del__(self):
         try:
@@ -110,8 +114,7 @@ class HeatMapEngine:
 
     # ---- RawHeatMapCollection.clear (heatmap.py:170-172) -----------------------------------------
     def clear(self) -> None:
-        self._held.clear()
-        self._pending.clear()
+        self._drop_recorded()
         self.touched.clear()
         self._touched_set.clear()
         if self.ctx is not None:
@@ -131,17 +134,16 @@ class HeatMapEngine:
         if not key.is_contiguous():
             key = key.contiguous()
         if self.defer_steps > 0:
-            if self._pending.get(layer, 0) >= self.defer_steps:
+            # record only: pointers cross the FFI in one daam_tap_qk_enqueue_many call per flush
+            n = self._pending.get(layer, 0)
+            if n >= self.defer_steps:
                 self.flush()
-            rc = self.lib.daam_tap_qk_enqueue(self.ctx, layer, query.data_ptr(), key.data_ptr(), c[7])
-            if rc == nat.E_STATE:           # shape / dtype changed inside the batch
-                self.flush()
-                rc = self.lib.daam_tap_qk_enqueue(self.ctx, layer, query.data_ptr(), key.data_ptr(), c[7])
-            if rc:
-                nat.check(rc)
-            self._held.append(query)
-            self._held.append(key)
-            self._pending[layer] = self._pending.get(layer, 0) + 1
+                n = 0
+            self._pending[layer] = n + 1
+            self._rec_layer.append(layer)
+            self._rec_q.append(query)
+            self._rec_k.append(key)
+            self._rec_desc.append(c[9])
         else:
             rc = self.lib.daam_tap_qk(self.ctx, layer, query.data_ptr(), key.data_ptr(), c[7], self.stream)
             if rc:
@@ -169,17 +171,36 @@ class HeatMapEngine:
             scale=float(scale),
             q_stride_b=hw * c, q_stride_h=d, q_stride_p=c,
             k_stride_b=tokens * c, k_stride_h=d, k_stride_t=c)
-        entry = (query.shape, key.shape, query.dtype, heads, scale, round_logits, factor, nat.byref(desc), desc)
+        # a shape change of a layer inside a deferred batch starts a new batch (the C side checks too)
+        if self._pending.get(layer, 0):
+            self.flush()
+        entry = (query.shape, key.shape, query.dtype, heads, scale, round_logits, factor, nat.byref(desc), desc,
+                 ctypes.addressof(desc))
         self._qk_cache[layer] = entry
         return entry
 
     def flush(self) -> None:
         """Run every recorded (deferred) tap; the held Q/K references are dropped afterwards
         (stream order keeps their memory valid until the kernel has consumed it)."""
-        if self.ctx is None or not self._pending:
+        n = len(self._rec_layer)
+        if self.ctx is None or n == 0:
             return
-        nat.check(self.lib.daam_tap_flush(self.ctx, self.stream))
-        self._held.clear()
+        layers = np.asarray(self._rec_layer, dtype=np.int32)
+        qp = np.fromiter((t.data_ptr() for t in self._rec_q), dtype=np.uint64, count=n)
+        kp = np.fromiter((t.data_ptr() for t in self._rec_k), dtype=np.uint64, count=n)
+        dp = np.asarray(self._rec_desc, dtype=np.uint64)
+        try:
+            nat.check(self.lib.daam_tap_qk_enqueue_many(self.ctx, n, layers.ctypes.data, qp.ctypes.data, kp.ctypes.data,
+                                                        dp.ctypes.data))
+            nat.check(self.lib.daam_tap_flush(self.ctx, self.stream))
+        finally:
+            self._drop_recorded()
+
+    def _drop_recorded(self) -> None:
+        self._rec_layer.clear()
+        self._rec_q.clear()
+        self._rec_k.clear()
+        self._rec_desc.clear()
         self._pending.clear()
 
     def tap_probs(self, layer: int, probs: torch.Tensor, factor: int) -> None:

@@ -104,6 +104,10 @@ int daam_reset(DaamCtx* ctx, void* stream);
  * holds attention_probs); bit-exact with the reference in the add. */
 int daam_tap_qk(DaamCtx* ctx, int layer, const void* q, const void* k, const DaamQKDesc* d, void* stream);
 int daam_tap_qk_enqueue(DaamCtx* ctx, int layer, const void* q, const void* k, const DaamQKDesc* d);
+/* the same as n daam_tap_qk_enqueue calls in order (all or nothing): lets a host runtime that
+ * records calls cheaply hand them over in one crossing of the FFI.  HOST arrays. */
+int daam_tap_qk_enqueue_many(DaamCtx* ctx, int n, const int32_t* layers, const void* const* q,
+                             const void* const* k, const DaamQKDesc* const* descs);
 int daam_tap_pending(DaamCtx* ctx, int* n_calls, int* max_steps);
 int daam_tap_flush(DaamCtx* ctx, void* stream);
 int daam_tap_probs(DaamCtx* ctx, int layer, const void* probs, int in_dtype, int batch_heads,
@@ -125,8 +129,8 @@ int daam_epilogue_normalize(float* maps, int n_rows, int side, void* stream);
 /* ---- word maps (next row f1) -------------------------------------------------------------
  * heatmap.py:121-123 + 77-93: mean of the planes `idx[0..n_idx)` (HOST int array) of
  * maps[*, side, side] -> bicubic to out_h x out_w -> (absolute ? id : min-max normalise with
- * eps 1e-8) -> (threshold > 0 ? (x > threshold) : x).  word_map[side*side] (optional, may be
- * NULL) receives the un-expanded mean plane; `out` [out_h, out_w] fp32;
+ * eps 1e-8) -> (threshold != 0 ? (x > threshold) : x).  word_map[side*side] (required) receives
+ * the un-expanded mean plane; `out` [out_h, out_w] fp32 (NULL: only the mean plane is computed);
  * `workspace` >= 2 floats of device scratch for the min/max. */
 int daam_word_heat_map(const float* maps, int side, const int32_t* idx, int n_idx, float* word_map,
                        float* out, int out_h, int out_w, int absolute, float threshold,
