@@ -280,6 +280,15 @@ def main():
                         traffic=traffic, bytes_per_launch=int(bytes_launch), ms_per_launch=round(tap_ms, 4),
                         steps_per_launch=spl, launches_per_generation=launches_per_gen,
                         achieved_at_survey_8d_bytes=round(survey_bytes / (tap_ms * 1e-3) / 1e9, 1))
+        # host cost of the per-layer call path for one generation (launches are asynchronous)
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for t in range(args.denoise_steps):
+            for (layer, heads, side, d), (q, k) in zip(layers, sets[t % len(sets)]):
+                eng.tap_qk(layer, q, k, heads, d ** -0.5, factor=max(0, latent_side // side) if side <= latent_side else 0)
+        eng.flush()
+        host_ms = (time.perf_counter() - th0) * 1e3
+        torch.cuda.synchronize()
         fin_ms = measure_finalize(eng, reps=20)
         fin_bytes = acc_total + 77 * 64 * 64 * 4
         fin_gbs = fin_bytes / (fin_ms * 1e-3) / 1e9
@@ -288,8 +297,9 @@ def main():
             extraction_overhead_ms_per_denoise_step=round((elapsed / args.steps * 1e3) / args.denoise_steps, 4),
             gpu_ms_per_denoise_step=round(launches_per_gen * tap_ms / args.denoise_steps, 4),
             gpu_bound_maps_per_s=round(1e3 / gpu_ms_per_gen, 1),
+            host_enqueue_ms_per_generation=round(host_ms, 3),
             raw_maps_per_s=round(world * args.steps * args.denoise_steps * sum(h for _, h, _, _ in layers) / elapsed, 1),
-            roofline_finalize=dict(bound='hbm', kernel='finalize_kernel', achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
+            roofline_finalize=dict(bound='hbm', kernel='finalize_same_kernel + finalize_up_kernel<32>', achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
                                    unit='GB/s', frac=round(fin_gbs / HBM_PEAK_GBS, 4), bytes_per_launch=int(fin_bytes),
                                    ms_per_launch=round(fin_ms, 4)),
         )

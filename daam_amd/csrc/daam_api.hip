@@ -16,7 +16,7 @@
 
 namespace daam {
 hipError_t launch_tap_generic(const TapLaunch&, int, int, int, hipStream_t, int*, int*);
-hipError_t launch_tap_mfma(const TapLaunch&, int acc_dtype, int max_d, hipStream_t, int*, int*);
+hipError_t launch_tap_mfma(const TapLaunch&, int acc_dtype, int max_d, int fast_exp, hipStream_t, int*, int*);
 bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t q_sp, int64_t k_st,
                         int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh);
 int tap_mfma_tile_pixels();
@@ -160,6 +160,7 @@ struct DaamCtx {
     void drop_pending() { pending.clear(); pending_count.clear(); pending_last.clear(); }
     int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
     int force_generic = 0;
+    int fast_exp = 0;
 };
 
 static size_t acc_elem(int dtype) { return dtype == DAAM_F16 ? 2 : 4; }
@@ -220,6 +221,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     }
     const char* fg = getenv("DAAM_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
+    const char* fe = getenv("DAAM_FAST_EXP");
+    c->fast_exp = fe && fe[0] == '1';
     *out = c;
     return 0;
 }
@@ -363,7 +366,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     L.total_wgs = L.one.heads_kept * L.one.tiles_per_head;
     L.wgs_per_xcd = (L.total_wgs + 7) / 8;
     c->last_block[0] = 256;
-    hipError_t e = mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+    hipError_t e = mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                         : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
                                              &c->last_grid[0], &c->last_lds[0]);
     if (e != hipSuccess) return fail((int)e, "tap launch: %s", hipGetErrorString(e));
@@ -492,7 +495,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         L.total_wgs = wg;
         L.wgs_per_xcd = (wg + 7) / 8;
         int grid = 0;
-        e = kd ? launch_tap_mfma(L, c->acc_dtype, max_d, s, &grid, &c->last_lds[0])
+        e = kd ? launch_tap_mfma(L, c->acc_dtype, max_d, c->fast_exp, s, &grid, &c->last_lds[0])
                : launch_tap_generic(L, in_dtype, c->acc_dtype, max_d, s, &grid, &c->last_lds[0]);
         grid_total += grid;
         if (e != hipSuccess) { rc = fail((int)e, "tap launch: %s", hipGetErrorString(e)); break; }

@@ -62,10 +62,12 @@ constexpr float kMasked = -1.0e30f;    // logit of the padding tokens: exp() und
 
 // e^d for d <= 0 to ~1 ulp: 2^(d*log2e) on v_exp_f32 with the rounding error of the product
 // (and the low part of log2e) folded back in:  2^t * (1 + err * ln2).
+template <bool FAST>
 __device__ __forceinline__ float exp_nonpos(float d) {
     const float L = 1.44269502162933349609375f;       // log2(e) rounded to f32
     const float Llo = 1.92596303e-08f;                // log2(e) - L
     const float t = d * L;
+    if (FAST) return __builtin_amdgcn_exp2f(t);       // |rel err| <~ 1e-6 for d >= -17 (below: prob rounds to 0)
     float err = __builtin_fmaf(d, L, -t);
     err = __builtin_fmaf(d, Llo, err);
     const float r = __builtin_amdgcn_exp2f(t);
@@ -83,17 +85,29 @@ template <> struct AccVec<_Float16> { static constexpr int kPerVec = 8; };
 template <> struct AccVec<float> { static constexpr int kPerVec = 4; };
 
 template <int KS, typename ACC_T>
-__global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
+constexpr size_t tap_mfma_lds_bytes() {
+    // K double buffer and the write-back staging tile are never live together: aliased
+    const size_t kb = 2 * (size_t)kTokRows * (KS * 32 + 16), st = (size_t)kTok * kMfmaPixels * sizeof(ACC_T);
+    return (kb > st ? kb : st) + (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);
+}
+
+// waves per SIMD the register allocator must leave room for: 4 for the fp16-sum SD/SDXL head dims
+template <int KS, typename ACC_T> constexpr int tap_mfma_min_waves() { return (KS <= 4 && sizeof(ACC_T) == 2) ? 4 : 2; }
+
+template <int KS, typename ACC_T, bool FAST_EXP>
+__global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T>())) void tap_mfma_kernel(const TapLaunch L)
 {
     constexpr int KROW = KS * 32 + 16;                        // bytes per K row in LDS
     constexpr int KBUF = kTokRows * KROW;                     // bytes per K buffer
     constexpr int KCH = (kTok * 2 * KS + 255) / 256;          // 16-B K pieces per thread per step
     constexpr int VEC = AccVec<ACC_T>::kPerVec;
     constexpr int PPR = kMfmaPixels / VEC;                    // 16-B pieces per staging row
+    constexpr size_t kPtrOff = tap_mfma_lds_bytes<KS, ACC_T>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);
 
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* kbuf = smem;                               // [2][KBUF]
-    ACC_T* stage = reinterpret_cast<ACC_T*>(smem + 2 * KBUF); // [kTok][kMfmaPixels]
+    ACC_T* stage = reinterpret_cast<ACC_T*>(smem);            // [kTok][kMfmaPixels], aliases kbuf
+    const void** sptr = reinterpret_cast<const void**>(smem + kPtrOff);
 
     const int wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
     if (wg < 0) return;
@@ -105,43 +119,34 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
     } else {
         lay = L.one;
     }
+    const int tid = threadIdx.x;
     // per-step q / k base pointers -> LDS once, so the step loop never waits on a dependent
     // global load (table fetch -> address -> data) on its critical path
-    const void** sptr = reinterpret_cast<const void**>(smem + 2 * KBUF + kTok * kMfmaPixels * sizeof(ACC_T));
     if (table) {
         const DAAM_GLOBAL TapPtr* ptrs = as_global<TapPtr>(L.ptrs) + lay.ptr_begin;
-        for (int i = threadIdx.x; i < lay.n_steps; i += 256) {
+        for (int i = tid; i < lay.n_steps; i += 256) {
             sptr[2 * i] = ptrs[i].q;
             sptr[2 * i + 1] = ptrs[i].k;
         }
-    } else if (threadIdx.x == 0) {
+    } else if (tid == 0) {
         sptr[0] = L.one_ptr.q;
         sptr[1] = L.one_ptr.k;
     }
-    __syncthreads();
-    auto step_q = [&](int s) -> const void* { return sptr[2 * s]; };
-    auto step_k = [&](int s) -> const void* { return sptr[2 * s + 1]; };
+    const int n_steps = lay.n_steps;
     const int nch = lay.head_dim >> 3;                        // 16-B pieces per q / k row
     const int rel = wg - lay.wg_begin;
     const int kh = rel / lay.tiles_per_head;
     const int p0 = (rel - kh * lay.tiles_per_head) * kMfmaPixels;
     const int bh = lay.bh_first + kh;
     const int b = bh / lay.heads, h = bh - b * lay.heads;
-    const int64_t q_off = b * lay.q_sb + h * lay.q_sh;
     const int64_t k_off = b * lay.k_sb + h * lay.k_sh;
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, g = lane >> 5;
     const int my_pixel = min(p0 + wave * 32 + n, lay.hw - 1);  // clamped: out-of-range columns are never stored
+    const int64_t q_row = b * lay.q_sb + h * lay.q_sh + (int64_t)my_pixel * lay.q_sp;
 
-    // zero the K padding pieces (head_dim not a multiple of 16: piece 2*KS-1) once, both buffers
-    if (nch < 2 * KS) {
-        for (int r = tid; r < 2 * kTokRows; r += 256)
-            *reinterpret_cast<float4v*>(kbuf + (r / kTokRows) * KBUF + (r % kTokRows) * KROW + nch * 16) = float4v{0, 0, 0, 0};
-    }
-
-    // ---- running sums -> registers --------------------------------------------------------
+    // ---- running sums -> registers (through the staging tile, 16-byte row pieces) --------------
     ACC_T run[kSlots];
     ACC_T* acc = reinterpret_cast<ACC_T*>(lay.acc) + (size_t)kh * kTok * lay.hw;
     if (!lay.fresh) {
@@ -161,44 +166,54 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
 #pragma unroll
         for (int i = 0; i < kSlots; ++i) run[i] = (ACC_T)0;
     }
+    __syncthreads();                                          // staging reads done; sptr visible
+    // zero the K padding pieces (head_dim not a multiple of 16: piece 2*KS-1) once, both buffers
+    if (nch < 2 * KS) {
+        for (int r = tid; r < 2 * kTokRows; r += 256)
+            *reinterpret_cast<float4v*>(kbuf + (r / kTokRows) * KBUF + (r % kTokRows) * KROW + nch * 16) = float4v{0, 0, 0, 0};
+    }
 
-    // ---- software pipeline: K(s+1) and Q(s+1) in flight while step s computes ----------------
-    // Two operand register sets used in ping-pong (loop unrolled by two, no register copies) and
-    // branch-free prefetch (addresses clamped instead of predicated) so that the compiler's
-    // s_waitcnt vmcnt(N) can leave the newest prefetch outstanding behind the MFMA / softmax.
-    const int n_steps = lay.n_steps;
-    // per-thread K piece coordinates (fixed for the whole launch)
+    // per-thread K piece coordinates (fixed for the whole launch); rows >= 77 are clamped duplicates
     int k_src[KCH], k_dst[KCH];
 #pragma unroll
     for (int j = 0; j < KCH; ++j) {
         const int c = tid + 256 * j;
         const int t = c / nch, ch = c - t * nch;
-        const int tc = min(t, kTok - 1);
-        k_src[j] = tc * (int)lay.k_st + ch * 8;                 // elements (clamped duplicate row when t >= 77)
+        k_src[j] = min(t, kTok - 1) * (int)lay.k_st + ch * 8;
         k_dst[j] = t < kTok ? t * KROW + ch * 16 : -1;
     }
-    const int64_t q_row = q_off + (int64_t)my_pixel * lay.q_sp;
-    auto issue_k = [&](int s, float4v (&kr)[KCH]) {
-        const _Float16* kp = reinterpret_cast<const _Float16*>(step_k(s)) + k_off;
+    float4v kreg[KCH];
+    half8 bq[KS];
+    auto issue_k = [&](int s) {
+        const _Float16* kp = reinterpret_cast<const _Float16*>(sptr[2 * s + 1]) + k_off;
 #pragma unroll
-        for (int j = 0; j < KCH; ++j) kr[j] = *as_global<float4v>(kp + k_src[j]);
+        for (int j = 0; j < KCH; ++j) kreg[j] = *as_global<float4v>(kp + k_src[j]);
     };
-    auto commit_k = [&](int buf, const float4v (&kr)[KCH]) {
+    auto commit_k = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < KCH; ++j)
-            if (k_dst[j] >= 0) *reinterpret_cast<float4v*>(kbuf + buf * KBUF + k_dst[j]) = kr[j];
+            if (k_dst[j] >= 0) *reinterpret_cast<float4v*>(kbuf + buf * KBUF + k_dst[j]) = kreg[j];
     };
-    auto issue_q = [&](int s, half8 (&bq)[KS]) {
-        const _Float16* qp = reinterpret_cast<const _Float16*>(step_q(s)) + q_row;
+    auto issue_q = [&](int s) {
+        const _Float16* qp = reinterpret_cast<const _Float16*>(sptr[2 * s]) + q_row;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int ch = min(2 * ks + g, nch - 1);
-            bq[ks] = *as_global<half8>(qp + ch * 8);
-        }
+        for (int ks = 0; ks < KS; ++ks) bq[ks] = *as_global<half8>(qp + min(2 * ks + g, nch - 1) * 8);
         if (nch < 2 * KS && g == 1) bq[KS - 1] = half8{0, 0, 0, 0, 0, 0, 0, 0};   // zero-padded last piece
     };
-    auto compute = [&](const half8 (&bq)[KS], int buf) {
-        const unsigned char* kb = kbuf + buf * KBUF;
+
+    // ---- step loop: one barrier per step ------------------------------------------------------
+    //   top:  barrier (K(s) committed by everyone; everyone is done reading the other buffer)
+    //   MFMA: S^T = K(s) Q(s)^T      (operands: LDS buffer s&1, bq)
+    //   then: issue the global loads of step s+1 (K -> kreg, Q -> bq; the operand registers are free
+    //         again) so that they fly under the softmax, the longest phase
+    //   softmax + accumulate in registers
+    //   end:  kreg -> LDS buffer (s+1)&1
+    issue_k(0);
+    issue_q(0);
+    commit_k(0);
+    for (int s = 0; s < n_steps; ++s) {
+        __syncthreads();
+        const unsigned char* kb = kbuf + (s & 1) * KBUF;
         floatx16 c0 = {0}, c1 = {0}, c2 = {0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -210,6 +225,10 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[ks], c1, 0, 0, 0);
             c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, bq[ks], c2, 0, 0, 0);
         }
+        const int nx = min(s + 1, n_steps - 1);               // branch-free: the last step re-fetches itself
+        issue_k(nx);
+        issue_q(nx);
+
         // logits: alpha in f32, then the baddbmm output rounding (skipped for upcast_attention)
         float x[kSlots];
 #pragma unroll
@@ -231,10 +250,10 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int i = 0; i < kSlots; i += 4) {
-            x[i] = exp_nonpos(x[i] - m);         s0 += x[i];
-            x[i + 1] = exp_nonpos(x[i + 1] - m); s1 += x[i + 1];
-            x[i + 2] = exp_nonpos(x[i + 2] - m); s2 += x[i + 2];
-            x[i + 3] = exp_nonpos(x[i + 3] - m); s3 += x[i + 3];
+            x[i] = exp_nonpos<FAST_EXP>(x[i] - m);         s0 += x[i];
+            x[i + 1] = exp_nonpos<FAST_EXP>(x[i + 1] - m); s1 += x[i + 1];
+            x[i + 2] = exp_nonpos<FAST_EXP>(x[i + 2] - m); s2 += x[i + 2];
+            x[i + 3] = exp_nonpos<FAST_EXP>(x[i + 3] - m); s3 += x[i + 3];
         }
         float sum = (s0 + s1) + (s2 + s3);
         sum += __shfl_xor(sum, 32, 64);
@@ -244,31 +263,9 @@ __global__ __launch_bounds__(256, 2) void tap_mfma_kernel(const TapLaunch L)
             const _Float16 prob = (_Float16)(x[i] * inv);                // probs.to(dtype)
             run[i] = run[i] + (ACC_T)prob;                               // heatmap.py:156
         }
-    };
-
-    float4v kreg[KCH];
-    half8 bA[KS], bB[KS];
-    issue_k(0, kreg);
-    issue_q(0, bA);
-    commit_k(0, kreg);
-    __syncthreads();
-    int s = 0;
-    for (; s + 1 < n_steps; s += 2) {
-        // step s (operands bA, K buffer 0); prefetch step s+1
-        issue_k(s + 1, kreg);
-        issue_q(s + 1, bB);
-        compute(bA, 0);
-        commit_k(1, kreg);
-        __syncthreads();
-        // step s+1 (operands bB, K buffer 1); prefetch step s+2 (clamped: the tail re-fetches the last step)
-        const int nx = min(s + 2, n_steps - 1);
-        issue_k(nx, kreg);
-        issue_q(nx, bA);
-        compute(bB, 1);
-        commit_k(0, kreg);
-        __syncthreads();
+        commit_k((s + 1) & 1);
     }
-    if (s < n_steps) compute(bA, 0);                                     // odd step count: last step
+    __syncthreads();                                          // all K reads done before the staging tile reuses the space
 
     // ---- write back: registers -> LDS [token][pixel] -> 16-byte row pieces -------------------
 #pragma unroll
@@ -302,34 +299,35 @@ int tap_mfma_tile_pixels() { return kMfmaPixels; }
 int tap_mfma_max_steps() { return kMaxStepsPerLaunch; }
 int tap_mfma_ksteps(int head_dim) { return (head_dim + 15) / 16; }
 
-template <int KS, typename ACC_T>
+template <int KS, typename ACC_T, bool FAST>
 static hipError_t launch_one(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out)
 {
-    const size_t lds = 2 * (size_t)kTokRows * (KS * 32 + 16) + (size_t)kTok * kMfmaPixels * sizeof(ACC_T) +
-                       (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);
+    const size_t lds = tap_mfma_lds_bytes<KS, ACC_T>();
     *lds_out = lds;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_mfma_kernel<KS, ACC_T>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_mfma_kernel<KS, ACC_T, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((tap_mfma_kernel<KS, ACC_T>), dim3(grid), dim3(256), lds, stream, L);
+    hipLaunchKernelGGL((tap_mfma_kernel<KS, ACC_T, FAST>), dim3(grid), dim3(256), lds, stream, L);
     return hipGetLastError();
 }
 
 // every layer of the launch has the same k-step count ceil(head_dim / 16) (host groups by it)
-hipError_t launch_tap_mfma(const TapLaunch& L, int acc_dtype, int max_d, hipStream_t stream, int* grid_out,
-                           int* lds_out)
+hipError_t launch_tap_mfma(const TapLaunch& L, int acc_dtype, int max_d, int fast_exp, hipStream_t stream,
+                           int* grid_out, int* lds_out)
 {
     const int grid = L.wgs_per_xcd * 8;
     *grid_out = grid;
     size_t lds = 0;
     hipError_t e = hipErrorInvalidValue;
     const int ks = tap_mfma_ksteps(max_d);
-#define DAAM_CASE(K)                                                                   \
-    case K:                                                                            \
-        e = acc_dtype == 0 ? launch_one<K, _Float16>(L, stream, grid, &lds)            \
-                           : launch_one<K, float>(L, stream, grid, &lds);              \
+#define DAAM_CASE(K)                                                                                  \
+    case K:                                                                                           \
+        if (fast_exp) e = acc_dtype == 0 ? launch_one<K, _Float16, true>(L, stream, grid, &lds)       \
+                                         : launch_one<K, float, true>(L, stream, grid, &lds);         \
+        else e = acc_dtype == 0 ? launch_one<K, _Float16, false>(L, stream, grid, &lds)               \
+                                : launch_one<K, float, false>(L, stream, grid, &lds);                 \
         break;
     switch (ks) {
         DAAM_CASE(1) DAAM_CASE(2) DAAM_CASE(3) DAAM_CASE(4) DAAM_CASE(5) DAAM_CASE(6) DAAM_CASE(7) DAAM_CASE(8)

@@ -316,7 +316,7 @@ def test_full_size_layer_properties(heads, side, d):
             gm = eng.global_heat_map(head_idx=1)
             assert torch.allclose(gm, acc[1].clamp(min=0), atol=1e-6)
         eng.close()
-    assert torch.equal(res[0], res[1])
+    assert torch.equal(res[0], res[1]), f'{(res[0] != res[1]).sum().item()} elements differ, max {(res[0] - res[1]).abs().max().item()}'
     eng = _engine()
     kc = k.clone()
     kc[:] = kc[:, :1]                                            # all keys identical -> uniform attention
