@@ -615,7 +615,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         int grid = 0, lds = 0;
         hipError_t e;
         if (cls == 0) {
-            L.n_chunks = std::max(1, std::min(n, env_chunks ? env_chunks : 8));
+            L.n_chunks = std::max(1, std::min(n, env_chunks ? env_chunks : 4));
             e = launch_finalize_same(L, c->acc_dtype, s, &grid);
         } else if (cls == 3) {
             L.n_chunks = std::max(1, std::min(n, 32));

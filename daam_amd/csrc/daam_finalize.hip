@@ -16,6 +16,7 @@
 namespace daam {
 
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 template <typename T> struct Plane;
@@ -74,9 +75,13 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
     const float* x3 = my + tix[lane * 4 + 3];
     const float wx0 = tw[lane * 4 + 0], wx1 = tw[lane * 4 + 1], wx2 = tw[lane * 4 + 2], wx3 = tw[lane * 4 + 3];
 
-    float acc[O];
+    // this lane's output column: acc2[i] = rows (P0 + 2i, P0 + 2i + 1); with P0 = 1 rows 0 and 63 in edge[]
+    constexpr int P0 = (R == 2) ? 1 : 0;
+    static_assert(src_floor<S, O>(P0) == src_floor<S, O>(P0 + 1), "paired output rows must share their taps");
+    float2v acc2[O / 2];
+    float edge[2] = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < O; ++i) acc[i] = 0.f;
+    for (int i = 0; i < O / 2; ++i) acc2[i] = float2v{0.f, 0.f};
 
     const int stride = gridDim.y * 4;
     int kidx = blockIdx.y * 4 + wave;
@@ -99,53 +104,126 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
         }
         if (kidx + stride < L.n_keys) fetch(kidx + stride);
         __builtin_amdgcn_wave_barrier();                       // wave-private tile: LDS ops of one wave stay in order
-        float h[S];
+        // x pass on row PAIRS (v_pk_fma_f32: two rows per instruction); h2[yp] = (h[2yp], h[2yp+1]).
+        // LDS gathers are issued XB row pairs ahead of their use so their latency overlaps.
+        float2v h2[S / 2];
+        constexpr int XB = 4;
 #pragma unroll
-        for (int y = 0; y < S; ++y)
-            h[y] = x0[y * S] * wx0 + x1[y * S] * wx1 + x2[y * S] * wx2 + x3[y * S] * wx3;
+        for (int y0 = 0; y0 < S / 2; y0 += XB) {
+            float2v t0[XB], t1[XB], t2[XB], t3[XB];
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int ra = 2 * (y0 + j) * S, rb = ra + S;
+                t0[j] = float2v{x0[ra], x0[rb]};
+                t1[j] = float2v{x1[ra], x1[rb]};
+                t2[j] = float2v{x2[ra], x2[rb]};
+                t3[j] = float2v{x3[ra], x3[rb]};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                float2v v = t0[j] * wx0;
+                v = __builtin_elementwise_fma(t1[j], float2v{wx1, wx1}, v);
+                v = __builtin_elementwise_fma(t2[j], float2v{wx2, wx2}, v);
+                v = __builtin_elementwise_fma(t3[j], float2v{wx3, wx3}, v);
+                h2[y0 + j] = v;
+            }
+        }
         __builtin_amdgcn_wave_barrier();
+        // y pass on OUTPUT row pairs that share their 4 source rows (R = 2: (1,2), (3,4), ..., rows 0
+        // and 63 alone; R = 4: (0,1), (2,3), ...): each source row is broadcast against the pair of
+        // its two coefficients.
+        auto hrow = [&](int r) { const int rc = clamp_row<S>(r); return h2[rc >> 1][rc & 1]; };
+        if (P0 == 1) {
+            const int fa = src_floor<S, O>(0), fb = src_floor<S, O>(O - 1);
+            const float* wa = tw + (0 % R) * 4;
+            const float* wb = tw + ((O - 1) % R) * 4;
+            float va = hrow(fa - 1) * wa[0], vb = hrow(fb - 1) * wb[0];
 #pragma unroll
-        for (int oy = 0; oy < O; ++oy) {
-            constexpr int dummy = 0; (void)dummy;
-            const int f = src_floor<S, O>(oy);
-            const float* w = tw + (oy % R) * 4;               // uniform: scalar loads
-            const float v = h[clamp_row<S>(f - 1)] * w[0] + h[clamp_row<S>(f)] * w[1] +
-                            h[clamp_row<S>(f + 1)] * w[2] + h[clamp_row<S>(f + 2)] * w[3];
-            acc[oy] += fmaxf(v, 0.f);
+            for (int a = 1; a < 4; ++a) {
+                va = __builtin_fmaf(hrow(fa - 1 + a), wa[a], va);
+                vb = __builtin_fmaf(hrow(fb - 1 + a), wb[a], vb);
+            }
+            edge[0] += fmaxf(va, 0.f);
+            edge[1] += fmaxf(vb, 0.f);
+        }
+#pragma unroll
+        for (int o = P0; o + 1 < O; o += 2) {
+            const int f = src_floor<S, O>(o);                  // == src_floor(o + 1) by construction
+            const float* w0 = tw + (o % R) * 4;               // uniform: scalar loads
+            const float* w1 = tw + ((o + 1) % R) * 4;
+            const float hv0 = hrow(f - 1);
+            float2v v = float2v{hv0, hv0} * float2v{w0[0], w1[0]};
+#pragma unroll
+            for (int a = 1; a < 4; ++a) {
+                const float hv = hrow(f - 1 + a);
+                v = __builtin_elementwise_fma(float2v{hv, hv}, float2v{w0[a], w1[a]}, v);
+            }
+            acc2[(o - P0) >> 1] += float2v{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
         }
     }
     __syncthreads();                                           // red[] zeroed
 #pragma unroll
-    for (int oy = 0; oy < O; ++oy) atomicAdd(&red[oy * O + lane], acc[oy]);     // ds_add_f32
+    for (int oy = 0; oy < O; ++oy) {
+        float v;
+        if (P0 == 1 && oy == 0) v = edge[0];
+        else if (P0 == 1 && oy == O - 1) v = edge[1];
+        else v = acc2[(oy - P0) >> 1][(oy - P0) & 1];
+        atomicAdd(&red[oy * O + lane], v);                     // ds_add_f32
+    }
     __syncthreads();
     float* out = L.out + (size_t)tok * O * O;
     for (int i = tid; i < O * O; i += 256) atomicAdd(out + i, red[i] * L.inv_n);
 }
 
-// side == out_side: out[t][i] += sum over this chunk's keys of max(plane[t][i], 0) / N
+// side == out_side: out[t][i] += sum over this chunk's keys of max(plane[t][i], 0) / N.
+// A wave owns 64 consecutive 16-byte pieces of one token plane; kBatch keys are in flight per
+// lane; the partial sums are transposed through a wave-private LDS tile so that the final
+// atomics are 256-byte coalesced rows instead of 64 scattered 32-byte sectors.
 template <typename ACC_T>
 __global__ __launch_bounds__(256) void finalize_same_kernel(const FinLaunch L)
 {
     using P = Plane<ACC_T>;
+    constexpr int E = P::kPerPiece;
+    constexpr int kBatch = 8;
+    __shared__ float tile[4][64 * (E + 1)];
     const int plane = L.out_side * L.out_side;
-    const int vec = blockIdx.x * 256 + threadIdx.x;            // one 16-byte piece of one token plane
-    const int per_tok = plane / P::kPerPiece;
-    if (vec >= L.tokens * per_tok) return;
-    const int tok = vec / per_tok, off = (vec - tok * per_tok) * P::kPerPiece;
-    float a[P::kPerPiece];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_id = blockIdx.x * 4 + wave;                 // wave -> 64 pieces
+    const int per_tok = plane / E;                             // pieces per token plane
+    const int waves_per_tok = (per_tok + 63) / 64;             // a wave never straddles two token planes
+    const int tok = wave_id / waves_per_tok;
+    if (tok >= L.tokens) return;
+    const int piece0 = (wave_id - tok * waves_per_tok) * 64;
+    const int off = (piece0 + lane) * E;
+    const bool valid = piece0 + lane < per_tok;
+    float a[E];
 #pragma unroll
-    for (int i = 0; i < P::kPerPiece; ++i) a[i] = 0.f;
-    int kidx = blockIdx.y;
+    for (int i = 0; i < E; ++i) a[i] = 0.f;
     const int stride = gridDim.y;
-#pragma unroll 4
-    for (; kidx < L.n_keys; kidx += stride) {
-        const ACC_T* src = reinterpret_cast<const ACC_T*>(L.keys[kidx].base) + (size_t)tok * plane + off;
-        const typename P::Piece piece = *as_global<typename P::Piece>(src);
-        P::clamp_add(piece, a);
-    }
-    float* out = L.out + (size_t)tok * plane + off;
+    for (int k0 = blockIdx.y; k0 < L.n_keys; k0 += stride * kBatch) {
+        typename P::Piece buf[kBatch];
 #pragma unroll
-    for (int i = 0; i < P::kPerPiece; ++i) atomicAdd(out + i, a[i] * L.inv_n);
+        for (int j = 0; j < kBatch; ++j) {
+            const int kk = min(k0 + j * stride, L.n_keys - 1);   // clamped duplicate, masked below
+            const ACC_T* src = reinterpret_cast<const ACC_T*>(L.keys[kk].base) + (size_t)tok * plane + off;
+            if (valid) buf[j] = *as_global<typename P::Piece>(src);
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j)
+            if (valid && k0 + j * stride < L.n_keys) P::clamp_add(buf[j], a);
+    }
+    float* t = tile[wave];
+#pragma unroll
+    for (int i = 0; i < E; ++i) t[lane * (E + 1) + i] = a[i] * L.inv_n;
+    __builtin_amdgcn_wave_barrier();
+    float* out = L.out + (size_t)tok * plane + piece0 * E;
+    const int span = min(64, per_tok - piece0) * E;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int e = i * 64 + lane;                           // element of the wave's contiguous span
+        if (e < span) atomicAdd(out + e, t[(e / E) * (E + 1) + (e % E)]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -153,8 +231,9 @@ hipError_t launch_finalize_same(const FinLaunch& L, int acc_dtype, hipStream_t s
 {
     const int plane = L.out_side * L.out_side;
     const int per = acc_dtype == 0 ? 8 : 4;
-    const int vecs = L.tokens * plane / per;
-    dim3 grid((vecs + 255) / 256, L.n_chunks);
+    // waves never straddle token planes: per-token piece count rounded up to whole waves
+    const int waves = L.tokens * ((plane / per + 63) / 64);
+    dim3 grid((waves + 3) / 4, L.n_chunks);
     *grid_out = grid.x * grid.y;
     if (acc_dtype == 0) hipLaunchKernelGGL((finalize_same_kernel<_Float16>), grid, dim3(256), 0, stream, L);
     else hipLaunchKernelGGL((finalize_same_kernel<float>), grid, dim3(256), 0, stream, L);
