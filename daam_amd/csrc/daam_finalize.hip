@@ -120,14 +120,17 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
                 t3[j] = float2v{x3[ra], x3[rb]};
             }
             __builtin_amdgcn_sched_barrier(0);
+            // tap-major: XB independent accumulation chains in flight (a dependent v_pk_fma_f32 cannot
+            // issue back-to-back)
+            float2v v[XB];
 #pragma unroll
-            for (int j = 0; j < XB; ++j) {
-                float2v v = t0[j] * wx0;
-                v = __builtin_elementwise_fma(t1[j], float2v{wx1, wx1}, v);
-                v = __builtin_elementwise_fma(t2[j], float2v{wx2, wx2}, v);
-                v = __builtin_elementwise_fma(t3[j], float2v{wx3, wx3}, v);
-                h2[y0 + j] = v;
-            }
+            for (int j = 0; j < XB; ++j) v[j] = t0[j] * wx0;
+#pragma unroll
+            for (int j = 0; j < XB; ++j) v[j] = __builtin_elementwise_fma(t1[j], float2v{wx1, wx1}, v[j]);
+#pragma unroll
+            for (int j = 0; j < XB; ++j) v[j] = __builtin_elementwise_fma(t2[j], float2v{wx2, wx2}, v[j]);
+#pragma unroll
+            for (int j = 0; j < XB; ++j) h2[y0 + j] = __builtin_elementwise_fma(t3[j], float2v{wx3, wx3}, v[j]);
         }
         __builtin_amdgcn_wave_barrier();
         // y pass on OUTPUT row pairs that share their 4 source rows (R = 2: (1,2), (3,4), ..., rows 0
@@ -147,19 +150,28 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
             edge[0] += fmaxf(va, 0.f);
             edge[1] += fmaxf(vb, 0.f);
         }
+        constexpr int YB = 8;                                  // independent output pairs in flight
+        constexpr int NPAIR = (O - P0) / 2;
 #pragma unroll
-        for (int o = P0; o + 1 < O; o += 2) {
-            const int f = src_floor<S, O>(o);                  // == src_floor(o + 1) by construction
-            const float* w0 = tw + (o % R) * 4;               // uniform: scalar loads
-            const float* w1 = tw + ((o + 1) % R) * 4;
-            const float hv0 = hrow(f - 1);
-            float2v v = float2v{hv0, hv0} * float2v{w0[0], w1[0]};
+        for (int p0 = 0; p0 < NPAIR; p0 += YB) {
+            float2v v[YB];
 #pragma unroll
-            for (int a = 1; a < 4; ++a) {
-                const float hv = hrow(f - 1 + a);
-                v = __builtin_elementwise_fma(float2v{hv, hv}, float2v{w0[a], w1[a]}, v);
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int j = 0; j < YB; ++j) {
+                    const int p = p0 + j;
+                    if (p < NPAIR) {
+                        const int o = P0 + 2 * p;
+                        const int f = src_floor<S, O>(o);      // == src_floor(o + 1) by construction
+                        const float hv = hrow(f - 1 + a);
+                        const float2v w = {tw[(o % R) * 4 + a], tw[((o + 1) % R) * 4 + a]};   // uniform: scalar loads
+                        v[j] = a == 0 ? float2v{hv, hv} * w : __builtin_elementwise_fma(float2v{hv, hv}, w, v[j]);
+                    }
+                }
             }
-            acc2[(o - P0) >> 1] += float2v{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+#pragma unroll
+            for (int j = 0; j < YB; ++j)
+                if (p0 + j < NPAIR) acc2[p0 + j] += float2v{fmaxf(v[j][0], 0.f), fmaxf(v[j][1], 0.f)};
         }
     }
     __syncthreads();                                           // red[] zeroed
