@@ -621,8 +621,9 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             L.n_chunks = std::max(1, std::min(n, 32));
             e = launch_finalize(L, c->acc_dtype, s, &grid, &lds);
         } else {
-            const int want = env_chunks ? env_chunks : 16;
-            L.n_chunks = std::max(1, std::min((n + 3) / 4, want));
+            // each wave takes keys first, first + 4*n_chunks, ...: at most 64 per wave
+            const int want = env_chunks ? env_chunks : 8;
+            L.n_chunks = std::max(std::max(1, std::min((n + 3) / 4, want)), (n + 255) / 256);
             e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, s, &grid);
         }
         if (e != hipSuccess) return fail((int)e, "finalize launch (class %d): %s", cls, hipGetErrorString(e));

@@ -83,26 +83,41 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
 #pragma unroll
     for (int i = 0; i < O / 2; ++i) acc2[i] = float2v{0.f, 0.f};
 
+    // this wave's keys: first, first + stride, ...   Their plane base pointers go to LDS once
+    // (no dependent table fetch per key), and the planes are fetched kDepth keys ahead: a wave's
+    // critical path is then one HBM latency per kDepth planes instead of two per plane.
+    constexpr int kDepth = 4;
+    constexpr int kMaxKeysPerWave = 64;
+    __shared__ const void* kbase[4][kMaxKeysPerWave];
     const int stride = gridDim.y * 4;
-    int kidx = blockIdx.y * 4 + wave;
-    typename P::Piece pre[PL];
-    auto fetch = [&](int k) {
-        const ACC_T* src = reinterpret_cast<const ACC_T*>(L.keys[k].base) + (size_t)tok * S * S;
+    const int first = blockIdx.y * 4 + wave;
+    const int nk = first < L.n_keys ? min((L.n_keys - first + stride - 1) / stride, kMaxKeysPerWave) : 0;
+    if (lane < nk) kbase[wave][lane] = as_global<FinKey>(L.keys)[first + lane * stride].base;
+    __builtin_amdgcn_wave_barrier();
+    typename P::Piece pre[kDepth][PL];
+    auto fetch = [&](int i, typename P::Piece (&dst)[PL]) {
+        const ACC_T* src = reinterpret_cast<const ACC_T*>(kbase[wave][i]) + (size_t)tok * S * S;
 #pragma unroll
         for (int j = 0; j < PL; ++j) {
             const int piece = lane + 64 * j;
-            if (piece < NP) pre[j] = *as_global<typename P::Piece>(src + piece * P::kPerPiece);
+            if (piece < NP) dst[j] = *as_global<typename P::Piece>(src + piece * P::kPerPiece);
         }
     };
-    if (kidx < L.n_keys) fetch(kidx);
-    for (; kidx < L.n_keys; kidx += stride) {
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d)
+        if (d < nk) fetch(d, pre[d]);
+    for (int i0 = 0; i0 < nk; i0 += kDepth) {
+#pragma unroll
+      for (int d = 0; d < kDepth; ++d) {
+        const int ki = i0 + d;
+        if (ki >= nk) break;
         float* mine = planes[wave];
 #pragma unroll
         for (int j = 0; j < PL; ++j) {
             const int piece = lane + 64 * j;
-            if (piece < NP) P::widen(pre[j], mine + piece * P::kPerPiece);
+            if (piece < NP) P::widen(pre[d][j], mine + piece * P::kPerPiece);
         }
-        if (kidx + stride < L.n_keys) fetch(kidx + stride);
+        if (ki + kDepth < nk) fetch(ki + kDepth, pre[d]);
         __builtin_amdgcn_wave_barrier();                       // wave-private tile: LDS ops of one wave stay in order
         // x pass on row PAIRS (v_pk_fma_f32: two rows per instruction); h2[yp] = (h[2yp], h[2yp+1]).
         // LDS gathers are issued XB row pairs ahead of their use so their latency overlaps.
@@ -173,6 +188,7 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
             for (int j = 0; j < YB; ++j)
                 if (p0 + j < NPAIR) acc2[p0 + j] += float2v{fmaxf(v[j][0], 0.f), fmaxf(v[j][1], 0.f)};
         }
+      }
     }
     __syncthreads();                                           // red[] zeroed
 #pragma unroll

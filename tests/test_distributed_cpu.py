@@ -1,0 +1,60 @@
+"""world_size-2 gloo test of the multi-GPU exchange (prompt sharding + one all_gather of final
+maps).  CPU only: the collective layer is exercised, not the kernels."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from daam_amd.distributed import gather_heat_maps, shard_indices
+
+
+def test_shard_indices_cover_everything_once():
+    for n in (0, 1, 5, 8, 33):
+        for world in (1, 2, 3, 8):
+            got = sorted(i for r in range(world) for i in shard_indices(n, r, world))
+            assert got == list(range(n))
+            sizes = [len(shard_indices(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_indices(4, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_items, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        mine = shard_indices(n_items, rank, world)
+        # item i's "heat map" is a [3, 4, 4] tensor filled with i + plane/10
+        local = torch.stack([torch.full((3, 4, 4), float(i)) + torch.arange(3).view(3, 1, 1) / 10 for i in mine]) \
+            if mine else torch.zeros(0, 3, 4, 4)
+        full = gather_heat_maps(local, n_items)
+        torch.save(full, os.path.join(out_dir, f'r{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_items', [4, 5, 1])
+def test_gather_world2_gloo(tmp_path, n_items):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_items, str(tmp_path)), nprocs=world, join=True)
+    want = torch.stack([torch.full((3, 4, 4), float(i)) + torch.arange(3).view(3, 1, 1) / 10 for i in range(n_items)])
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f'r{r}.pt'))
+        assert torch.equal(got, want)
+
+
+def test_gather_single_process_passthrough():
+    x = torch.randn(3, 2, 2)
+    assert gather_heat_maps(x, 3) is x
+    with pytest.raises(ValueError):
+        gather_heat_maps(x, 4)

@@ -1,0 +1,270 @@
+"""CPU tests of everything above the kernels: the C ABI surface (library loads, exports exactly
+what include/daam_hip.h declares, fails loudly without a GPU), the hooking framework, the locator,
+token merge indices, the engine's deferred-tap bookkeeping (against a recording fake of the native
+library -- test-only, the product has no fallback), and the torch port used for the timed baselines."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_pipe, load_golden
+from oracle import fake_diffusers as fd
+from oracle import heatmap_oracle as ho
+
+
+# ------------------------------------------------------------------------------------------------
+# C ABI
+# ------------------------------------------------------------------------------------------------
+def _header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'daam_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(daam_[a-z_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    from daam_amd import _native
+    lib = _native.load()
+    declared = _header_symbols()
+    assert declared == sorted(_native.EXPORTS), 'include/daam_hip.h and daam_amd/_native.py disagree'
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.daam_abi_version() == 1
+    assert ctypes.sizeof(_native.QKDesc) == 80          # 8 x 4 bytes + 6 x 8 bytes, no padding surprises
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_context_creation_fails_loudly_without_gpu():
+    from daam_amd import _native
+    lib = _native.load()
+    ctx = ctypes.c_void_p()
+    rc = lib.daam_ctx_create(4, 77, 64, 0, ctypes.byref(ctx))
+    assert rc != 0 and not ctx.value
+    with pytest.raises(_native.DaamError):
+        _native.check(rc)
+    assert lib.daam_ctx_create(4, 99, 64, 0, ctypes.byref(ctx)) == -1        # DAAM_E_INVALID: tokens > 80
+    assert b'tokens' in lib.daam_last_error()
+    assert lib.daam_tap_flush(None, None) == -1
+
+
+# ------------------------------------------------------------------------------------------------
+# hook framework + locator (reference hook.py)
+# ------------------------------------------------------------------------------------------------
+def test_object_hooker_semantics():
+    from daam_amd.hook import AggregateHooker, ObjectHooker
+
+    class Thing:
+        def f(self, x):
+            return x + 1
+
+    class H(ObjectHooker):
+        def _hooked_f(hk, thing, x):
+            return 10 * hk.monkey_super('f', x)
+
+        def _hook_impl(self):
+            self.monkey_patch('f', self._hooked_f)
+            self.monkey_patch('missing', self._hooked_f, strict=False)
+
+    t = Thing()
+    h = H(t)
+    with pytest.raises(RuntimeError, match='Module is not hooked'):
+        h.unhook()
+    with h:
+        assert t.f(1) == 20
+        with pytest.raises(RuntimeError, match='Already hooked module'):
+            h.hook()
+    assert t.f(1) == 2 and not h.hooked
+    with pytest.raises(AttributeError):
+        h.monkey_patch('missing', None)
+    agg = AggregateHooker([H(Thing()), H(Thing())])
+    agg.register_hook(H(Thing()))
+    with agg:
+        assert all(x.hooked for x in agg.module)
+    assert not any(x.hooked for x in agg.module)
+
+
+@pytest.mark.parametrize('kind,n,n_mid', [('sd15', 15, 16), ('sdxl', 60, 70)])
+def test_locator_order_matches_oracle(kind, n, n_mid):
+    from daam_amd.hook import UNetCrossAttentionLocator
+    unet = fd.FakeUNet(kind, mini=True)
+    for restrict, mid in [(None, False), (None, True), ({0}, False), ({0, 2}, True)]:
+        loc = UNetCrossAttentionLocator(restrict=restrict, locate_middle_block=mid)
+        got = loc.locate(unet)
+        want, names = ho.locate(unet, restrict, mid)
+        assert [id(m) for m in got] == [id(m) for m in want]
+        assert loc.layer_names == names
+    assert len(UNetCrossAttentionLocator().locate(unet)) == n
+    assert len(UNetCrossAttentionLocator(locate_middle_block=True).locate(unet)) == n_mid
+
+
+def test_layer_names_match_reference_golden(golden_case):
+    from daam_amd.hook import UNetCrossAttentionLocator
+    name, z, meta = golden_case
+    pipe = golden_pipe(meta)
+    loc = UNetCrossAttentionLocator()
+    loc.locate(pipe.unet)
+    assert loc.layer_names == json.loads(str(z['layer_names']))
+
+
+def test_token_merge_indices():
+    from daam_amd.utils import compute_token_merge_indices
+    tok = fd.FakeTokenizer()
+    prompt = 'A photo of a Monkey riding a bicycle and a monkey'
+    assert compute_token_merge_indices(tok, prompt, 'monkey') == ([5, 12], None)
+    assert compute_token_merge_indices(tok, prompt, 'bicycle') == ([8, 9], None)      # two sub-word pieces
+    assert compute_token_merge_indices(tok, prompt, 'bicycle', offset_idx=1) == ([9, 10], None)
+    assert compute_token_merge_indices(tok, prompt, 'x', word_idx=3) == ([4], 3)
+    with pytest.raises(ValueError, match='Search word cat not found in prompt!'):
+        compute_token_merge_indices(tok, prompt, 'Cat')
+    toks = tok.tokenize(prompt.lower())
+    assert ho.token_merge_indices(toks, tok.tokenize('bicycle'), 'bicycle')[0] == [8, 9]
+
+
+# ------------------------------------------------------------------------------------------------
+# trace on a CPU pipeline: hooks install / restore; the tap refuses CPU tensors
+# ------------------------------------------------------------------------------------------------
+def test_trace_installs_and_restores_processors():
+    import daam_amd
+    z, meta = load_golden('sd15_f32')
+    pipe = golden_pipe(meta)
+    attn = [s.module for s in pipe.unet.execution_order()]
+    before = [a.processor for a in attn]
+    orig_check = pipe.check_inputs
+    tc = daam_amd.trace(pipe, low_memory=True)
+    assert tc.latent_hw == 4096 and len(tc.layer_names) == 6           # restrict={0}: one per block
+    tc = daam_amd.trace(pipe)
+    with tc:
+        hooked = [a for a in attn if type(a.processor).__name__ == 'UNetCrossAttentionHooker']
+        assert len(hooked) == 15                                        # mid block not hooked without save/load heads
+        assert [a.processor.layer_idx for a in ho.locate(pipe.unet)[0]] == list(range(15))
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            pipe('a dog', num_inference_steps=1)
+        assert tc.last_prompt == 'a dog'
+        with pytest.raises(RuntimeError, match='Did you forget'):
+            tc.compute_global_heat_map()
+    assert [a.processor for a in attn] == before
+    assert pipe.check_inputs == orig_check
+    assert daam_amd.trace is daam_amd.DiffusionHeatMapHooker
+    pipe768 = fd.make_pipe('sd15', sample_size=96, mini=True)          # SD-2.x 768: 96x96 latents
+    assert daam_amd.trace(pipe768).latent_hw == 9216
+    with pytest.raises(ValueError):
+        daam_amd.trace(pipe, tap='nope')
+
+
+# ------------------------------------------------------------------------------------------------
+# engine bookkeeping against a recording fake of libdaam_hip (test-only)
+# ------------------------------------------------------------------------------------------------
+class _FakeLib:
+    def __init__(self):
+        self.calls = []
+
+    def __getattr__(self, name):
+        if not name.startswith('daam_'):
+            raise AttributeError(name)
+
+        def fn(*args):
+            self.calls.append((name, args))
+            if name == 'daam_ctx_create':
+                args[-1]._obj.value = 1234
+            if name == 'daam_key_offset':
+                return 0
+            return 0
+        return fn
+
+    def names(self):
+        return [c[0] for c in self.calls]
+
+
+@pytest.fixture
+def fake_engine(monkeypatch):
+    from daam_amd import engine as E
+    lib = _FakeLib()
+    monkeypatch.setattr(E.nat, 'load', lambda: lib)
+    monkeypatch.setattr(E.HeatMapEngine, '_require_device',
+                        lambda self, t: setattr(self, 'device', torch.device('cpu')))
+    monkeypatch.setattr(E.HeatMapEngine, 'stream', property(lambda self: 0))
+    monkeypatch.setattr(torch.cuda, 'device', lambda d: __import__('contextlib').nullcontext())
+    return E, lib
+
+
+def test_engine_deferred_bookkeeping(fake_engine):
+    E, lib = fake_engine
+    eng = E.HeatMapEngine(3, defer_steps=2)
+    q = [torch.zeros(2, 64, 16, dtype=torch.float16) for _ in range(3)]
+    k = [torch.zeros(2, 77, 16, dtype=torch.float16) for _ in range(3)]
+    for step in range(5):
+        for layer in (2, 0, 1):                       # execution order != locator order
+            eng.tap_qk(layer, q[layer], k[layer], heads=2, scale=0.35, factor=8 // 8 or 1)
+    # 5 steps at 2 per launch: flushed after steps 2 and 4 (when step 3 / 5 arrive), 3 taps still recorded
+    assert lib.names().count('daam_tap_flush') == 2
+    many = [c for c in lib.calls if c[0] == 'daam_tap_qk_enqueue_many']
+    assert [c[1][1] for c in many] == [6, 6]
+    assert len(eng._rec_layer) == 3 and eng.touched == [2, 0, 1]
+    assert eng.keys()[:2] == [(1, 2, 0), (1, 2, 1)]
+    list(eng.items())                                  # reading the sums flushes the rest
+    assert lib.names().count('daam_tap_flush') == 3 and not eng._rec_layer
+    assert lib.names().count('daam_layer_configure') == 3
+    # a shape change of a layer mid-batch starts a new batch and a new buffer
+    eng.tap_qk(0, q[0], k[0], 2, 0.35, 1)
+    eng.tap_qk(0, torch.zeros(2, 256, 16, dtype=torch.float16), k[0], 2, 0.35, 1)
+    assert lib.names().count('daam_tap_flush') == 4 and lib.names().count('daam_layer_configure') == 4
+    eng.clear()                                        # RawHeatMapCollection.clear: drop recorded taps, zero sums
+    assert not eng._rec_layer and not eng.touched and lib.names()[-1] == 'daam_reset'
+    with pytest.raises(LookupError):
+        eng.global_heat_map()
+    eng.close()
+    assert lib.names()[-1] == 'daam_ctx_destroy'
+
+
+def test_engine_immediate_mode_and_dtype_rules(fake_engine):
+    E, lib = fake_engine
+    eng = E.HeatMapEngine(2, defer_steps=0)
+    eng.tap_qk(0, torch.zeros(2, 64, 16, dtype=torch.float16), torch.zeros(2, 77, 16, dtype=torch.float16), 2, 0.35, 1)
+    assert 'daam_tap_qk' in lib.names() and 'daam_tap_qk_enqueue_many' not in lib.names()
+    assert eng.acc_dtype == torch.float16 and eng.acc[0].shape == (2, 77, 8, 8)
+    with pytest.raises(RuntimeError, match='fp32 activations'):
+        eng.tap_qk(1, torch.zeros(2, 64, 16), torch.zeros(2, 77, 16), 2, 0.35, 1)
+    eng32 = E.HeatMapEngine(1, accumulate='float32')
+    eng32.tap_probs(0, torch.zeros(4, 64, 77, dtype=torch.float16), factor=1)
+    assert eng32.acc_dtype == torch.float32
+    with pytest.raises(RuntimeError, match='unsupported pipeline dtype'):
+        E.HeatMapEngine(1).tap_qk(0, torch.zeros(2, 64, 16, dtype=torch.bfloat16),
+                                  torch.zeros(2, 77, 16, dtype=torch.bfloat16), 2, 0.35, 1)
+    with pytest.raises(ValueError):
+        E.HeatMapEngine(1, accumulate='bf16')
+
+
+# ------------------------------------------------------------------------------------------------
+# the torch port (bench baselines) is pinned to the same golden vectors
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['sd15_f32', 'sdxl_f32', 'sd15_f16'])
+def test_torch_port_matches_reference_golden(name):
+    from oracle import torch_hooks as th
+    z, meta = load_golden(name)
+    pipe = golden_pipe(meta)
+    modules, _ = ho.locate(pipe.unet)
+    index_of = {id(m): i for i, m in enumerate(modules)}
+    lat = ho.latent_hw_for(pipe.unet.config.sample_size, pipe.vae_scale_factor)
+    raw = th.RawMaps()
+    for step in range(meta['steps']):
+        for i, spec in enumerate(pipe.unet.execution_order()):
+            li = index_of.get(id(spec.module))
+            if li is None:
+                continue
+            a = spec.module
+            q = a.head_to_batch_dim(a.to_q(pipe.hidden_states(i, spec, step)))
+            k = a.head_to_batch_dim(a.to_k(pipe.context(i, spec)))
+            th.tap(raw, li, th.attention_probs(q, k, a.scale), lat)
+    assert np.array_equal(np.asarray([k for k, _ in raw], dtype=np.int32), z['keys'])
+    n_rows = len(pipe.tokenizer.tokenize(meta['prompt'])) + 2
+    for vn, kw in json.loads(str(z['variants'])).items():
+        got = th.global_heat_map(raw, lat, n_rows=n_rows, **kw).numpy()
+        tol = 2e-6 if meta['dtype'] == 'float32' else 2e-4
+        np.testing.assert_allclose(got, z[f'global_{vn}'], rtol=0, atol=tol * max(1.0, float(np.abs(z[f'global_{vn}']).max())))
+    assert len(th.topology('sdxl')) == 60 and sum(h for _, h, _, _ in th.topology('sdxl')) == 1100
+    assert len(th.topology('sd15')) == 15 and sum(h for _, h, _, _ in th.topology('sd15')) == 120
