@@ -25,7 +25,7 @@ int tap_mfma_max_steps();
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
 hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
-hipError_t launch_finalize_up(const FinLaunch&, int side, int, hipStream_t, int*);
+hipError_t launch_finalize_up(const FinLaunch&, int side, int, int mfma_ok, hipStream_t, int*);
 bool finalize_up_supported(int side, int out_side);
 hipError_t launch_normalize(float*, int, int, hipStream_t);
 hipError_t launch_word(const float*, int, const int32_t*, int, float*, float*, int, int, int, float, float*,
@@ -154,6 +154,8 @@ struct DaamCtx {
     int16_t* d_tab_idx = nullptr;
     float* d_tab_w = nullptr;
     std::vector<int> tab_sides;
+    std::vector<int> tab_fp16_exact;   // every (border-merged) tap weight is an fp16 number
+    int no_mfma_finalize = 0;
     std::vector<Pending> pending;
     std::vector<int> pending_count;   // per layer: recorded steps
     std::vector<int> pending_last;    // per layer: index of its newest entry in `pending`
@@ -221,6 +223,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     }
     const char* fg = getenv("DAAM_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
+    const char* nm = getenv("DAAM_NO_MFMA_FINALIZE");
+    c->no_mfma_finalize = nm && nm[0] == '1';
     const char* fe = getenv("DAAM_FAST_EXP");
     c->fast_exp = fe && fe[0] == '1';
     *out = c;
@@ -275,6 +279,16 @@ int daam_layer_configure(DaamCtx* c, int layer, int heads, int side, int factor,
             HIP_TRY(hipMemcpy(c->d_tab_idx + (size_t)tab * c->out_side * 4, idx.data(), idx.size() * sizeof(int16_t), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(c->d_tab_w + (size_t)tab * c->out_side * 4, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
             c->tab_sides.push_back(side);
+            // can the banded tap matrix be an fp16 MFMA operand without rounding?
+            int exact = 1;
+            for (int j = 0; j < c->out_side && exact; ++j)
+                for (int a = 0; a < 4 && exact; ++a) {
+                    float merged = 0.f;                    // taps clamped onto the same border column add up
+                    for (int b2 = 0; b2 < 4; ++b2)
+                        if (idx[j * 4 + b2] == idx[j * 4 + a]) merged += w[j * 4 + b2];
+                    exact = ((float)(_Float16)merged == merged) && ((float)(_Float16)w[j * 4 + a] == w[j * 4 + a]);
+                }
+            c->tab_fp16_exact.push_back(exact);
         }
         l.tab = tab;
     }
@@ -624,7 +638,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             // each wave takes keys first, first + 4*n_chunks, ...: at most 64 per wave
             const int want = env_chunks ? env_chunks : 8;
             L.n_chunks = std::max(std::max(1, std::min((n + 3) / 4, want)), (n + 255) / 256);
-            e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, s, &grid);
+            e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, c->tab_fp16_exact[keys[cls][0].tab] && !c->no_mfma_finalize, s, &grid);
         }
         if (e != hipSuccess) return fail((int)e, "finalize launch (class %d): %s", cls, hipGetErrorString(e));
         c->last_grid[1] += grid;

@@ -204,6 +204,180 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
     for (int i = tid; i < O * O; i += 256) atomicAdd(out + i, red[i] * L.inv_n);
 }
 
+// ---------------------------------------------------------------------------------------
+// x2 (32 -> 64) for fp16 planes, no LDS on the data path.
+//   x pass = T[y][ox] = sum_x A[y][x] Wx[ox][x] on the matrix cores (v_mfma_f32_32x32x16_f16): the
+//   A operand is the plane itself, 16 bytes per lane straight from HBM (lane = source row y, half
+//   g -> columns 16ks+8g..+7); the B operand is the banded 32x64 tap matrix built once per wave from
+//   the host tables (every tap weight of the x2 bicubic, and every border-merged sum of them, is
+//   exactly representable in fp16 -- checked on the host, else the LDS kernel is used).  Products of
+//   two fp16 values are exact in f32 and at most 4 are non-zero per output, so T equals the
+//   reference's f32 x interpolation up to the summation order.
+//   The C/D layout leaves lane (j, g) with column ox = j (+32 for the second tile) and rows
+//   {8b+4g+r}: 8 v_permlane32_swap per tile regroup that into rows [16g, 16g+16) of the column,
+//   2 more swaps fetch the two halo rows on each side from the partner lane (border lanes clamp),
+//   and the y pass + clamp + accumulate run on registers with compile-time row taps; lane half g
+//   owns output rows [32g, 32g+32) of its column.
+// ---------------------------------------------------------------------------------------
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void swap32(float& x, float& y) {
+    // x <- {x.lo, y.lo}, y <- {x.hi, y.hi}   (lo / hi = lanes 0-31 / 32-63)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]);
+    y = __uint_as_float(r[1]);
+}
+
+__global__ __launch_bounds__(256) void finalize_up32_mfma_kernel(const FinLaunch L)
+{
+    constexpr int S = 32, O = 64;
+    constexpr int kDepth = 4, kMaxKeysPerWave = 64;
+    __shared__ const void* kbase[4][kMaxKeysPerWave];
+    __shared__ __align__(16) float red[O * O];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, g = lane >> 5;
+    const int tok = blockIdx.x;
+    for (int i = tid; i < O * O; i += 256) red[i] = 0.f;
+
+    const int tab = as_global<FinKey>(L.keys)[0].tab;
+    const int16_t* tix = L.tab_idx + (size_t)tab * O * 4;
+    const float* tw = L.tab_w + (size_t)tab * O * 4;
+
+    // B operand: wb[nt][ks][e] = Wx[ox = 32nt + n][x = 16ks + 8g + e]
+    half8 wb[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int ox = 32 * nt + n;
+        int ix[4];
+        float wv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { ix[a] = tix[ox * 4 + a]; wv[a] = tw[ox * 4 + a]; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int x = 16 * ks + 8 * g + e;
+                float w = 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) w += (ix[a] == x) ? wv[a] : 0.f;
+                wb[nt][ks][e] = (_Float16)w;
+            }
+    }
+    // y weights: output row parity 0 (t = 0.75) and 1 (t = 0.25)
+    float wy[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wy[p][a] = tw[p * 4 + a];
+
+    // acc[nt][o'] = output row 32g + o' of column 32nt + n
+    float acc[2][32];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[nt][i] = 0.f;
+
+    const int stride = gridDim.y * 4;
+    const int first = blockIdx.y * 4 + wave;
+    const int nk = first < L.n_keys ? min((L.n_keys - first + stride - 1) / stride, kMaxKeysPerWave) : 0;
+    if (lane < nk) kbase[wave][lane] = as_global<FinKey>(L.keys)[first + lane * stride].base;
+    __builtin_amdgcn_wave_barrier();
+
+    half8 pre[kDepth][2];
+    auto fetch = [&](int i, half8 (&dst)[2]) {
+        const _Float16* src = reinterpret_cast<const _Float16*>(kbase[wave][i]) + (size_t)tok * S * S + n * S + 8 * g;
+        dst[0] = *as_global<half8>(src);
+        dst[1] = *as_global<half8>(src + 16);
+    };
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d)
+        if (d < nk) fetch(d, pre[d]);
+
+    for (int i0 = 0; i0 < nk; i0 += kDepth) {
+#pragma unroll
+      for (int d = 0; d < kDepth; ++d) {
+        const int ki = i0 + d;
+        if (ki >= nk) break;
+        floatx16 c[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            c[nt] = floatx16{0};
+            c[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][0], wb[nt][0], c[nt], 0, 0, 0);
+            c[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][1], wb[nt][1], c[nt], 0, 0, 0);
+        }
+        if (ki + kDepth < nk) fetch(ki + kDepth, pre[d]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            // e[q + 2] = source row 16g + q of this lane's column, q = -2 .. 17
+            float e[20];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = c[nt][4 * b + r], y = c[nt][4 * (b + 2) + r];
+                    swap32(x, y);
+                    e[2 + 8 * b + r] = x;                       // row 16g + 8b + r
+                    e[2 + 8 * b + 4 + r] = y;                   // row 16g + 8b + 4 + r
+                }
+            {
+                float xa = e[2 + 0], ya = e[2 + 14], xb = e[2 + 1], yb = e[2 + 15];
+                swap32(xa, ya);                                 // upper lanes: xa = partner's q=14; lower: ya = partner's q=0
+                swap32(xb, yb);                                 // upper lanes: xb = partner's q=15; lower: yb = partner's q=1
+                e[0] = g ? xa : e[2];                           // rows -2, -1 clamp to row 0 for the lower half
+                e[1] = g ? xb : e[2];
+                e[18] = g ? e[17] : ya;                         // rows 32, 33 clamp to row 31 for the upper half
+                e[19] = g ? e[17] : yb;
+            }
+            // output row o' (global 32g + o'): taps local q = f'-1 .. f'+2, f' = floor(o'/2 - 1/4)
+            {
+                // singles o' = 0 (f' = -1) and o' = 31 (f' = 15)
+                float v0 = e[0] * wy[0][0];
+                v0 = __builtin_fmaf(e[1], wy[0][1], v0);
+                v0 = __builtin_fmaf(e[2], wy[0][2], v0);
+                v0 = __builtin_fmaf(e[3], wy[0][3], v0);
+                acc[nt][0] += fmaxf(v0, 0.f);
+                float v1 = e[16] * wy[1][0];
+                v1 = __builtin_fmaf(e[17], wy[1][1], v1);
+                v1 = __builtin_fmaf(e[18], wy[1][2], v1);
+                v1 = __builtin_fmaf(e[19], wy[1][3], v1);
+                acc[nt][31] += fmaxf(v1, 0.f);
+            }
+            // pairs (o', o'+1), o' odd: both have f' = (o'-1)/2, taps q = f'-1 .. f'+2
+            constexpr int YB = 5;
+#pragma unroll
+            for (int p0 = 0; p0 < 15; p0 += YB) {
+                float2v v[YB];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int j = 0; j < YB; ++j) {
+                        const int op = 1 + 2 * (p0 + j);                  // odd o'
+                        const int f = (op - 1) / 2;
+                        const float hv = e[2 + f - 1 + a];
+                        const float2v w = {wy[1][a], wy[0][a]};          // (odd row, even row)
+                        v[j] = a == 0 ? float2v{hv, hv} * w : __builtin_elementwise_fma(float2v{hv, hv}, w, v[j]);
+                    }
+#pragma unroll
+                for (int j = 0; j < YB; ++j) {
+                    const int op = 1 + 2 * (p0 + j);
+                    acc[nt][op] += fmaxf(v[j][0], 0.f);
+                    acc[nt][op + 1] += fmaxf(v[j][1], 0.f);
+                }
+            }
+        }
+      }
+    }
+    __syncthreads();                                           // red[] zeroed
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) atomicAdd(&red[(32 * g + i) * O + 32 * nt + n], acc[nt][i]);     // ds_add_f32
+    __syncthreads();
+    float* out = L.out + (size_t)tok * O * O;
+    for (int i = tid; i < O * O; i += 256) atomicAdd(out + i, red[i] * L.inv_n);
+}
+
 // side == out_side: out[t][i] += sum over this chunk's keys of max(plane[t][i], 0) / N.
 // A wave owns 64 consecutive 16-byte pieces of one token plane; kBatch keys are in flight per
 // lane; the partial sums are transposed through a wave-private LDS tile so that the final
@@ -270,11 +444,13 @@ hipError_t launch_finalize_same(const FinLaunch& L, int acc_dtype, hipStream_t s
 
 bool finalize_up_supported(int side, int out_side) { return out_side == 64 && (side == 32 || side == 16); }
 
-hipError_t launch_finalize_up(const FinLaunch& L, int side, int acc_dtype, hipStream_t stream, int* grid_out)
+hipError_t launch_finalize_up(const FinLaunch& L, int side, int acc_dtype, int mfma_ok, hipStream_t stream, int* grid_out)
 {
     dim3 grid(L.tokens, L.n_chunks);
     *grid_out = grid.x * grid.y;
-    if (side == 32) {
+    if (side == 32 && acc_dtype == 0 && mfma_ok) {
+        hipLaunchKernelGGL(finalize_up32_mfma_kernel, grid, dim3(256), 0, stream, L);
+    } else if (side == 32) {
         if (acc_dtype == 0) hipLaunchKernelGGL((finalize_up_kernel<_Float16, 32>), grid, dim3(256), 0, stream, L);
         else hipLaunchKernelGGL((finalize_up_kernel<float, 32>), grid, dim3(256), 0, stream, L);
     } else {
