@@ -49,6 +49,37 @@ template <int S, int O> __device__ __forceinline__ constexpr int src_floor(int o
 }
 template <int S> __device__ __forceinline__ constexpr int clamp_row(int v) { return v < 0 ? 0 : (v > S - 1 ? S - 1 : v); }
 
+// Sum the four waves' register-resident [64,64] partial maps and add the result (x 1/N) into
+// `out` with one coalesced f32 atomic per element.  Plain LDS stores / loads in two rounds: LDS
+// float atomics (ds_add_f32) measured ~1000 cycles per wave-instruction here and were 50% of the
+// kernel.  get(i) / add(i, v) access element i (compile-time) of the caller's registers, off(i) is
+// its offset in the row-major tile (consecutive lanes -> consecutive offsets).
+template <typename Get, typename Add, typename Off>
+__device__ __forceinline__ void wg_reduce_flush(float* tiles /* [2][64*64] */, int wave, Get get, Add add, Off off,
+                                                float* out, float inv_n)
+{
+    constexpr int O = 64;
+    if (wave >= 2) {
+#pragma unroll
+        for (int i = 0; i < O; ++i) tiles[(wave - 2) * O * O + off(i)] = get(i);
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int i = 0; i < O; ++i) add(i, tiles[wave * O * O + off(i)]);
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int i = 0; i < O; ++i) tiles[off(i)] = get(i);
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < O; ++i) atomicAdd(out + off(i), (get(i) + tiles[off(i)]) * inv_n);
+    }
+}
+
 template <typename ACC_T, int S>
 __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
 {
@@ -59,11 +90,10 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
     constexpr int PL = (NP + 63) / 64;                        // pieces per lane
 
     __shared__ __align__(16) float planes[4][S * S];
-    __shared__ __align__(16) float red[O * O];
+    __shared__ __align__(16) float red[2 * O * O];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tok = blockIdx.x;
-    for (int i = tid; i < O * O; i += 256) red[i] = 0.f;
 
     const int tab = L.keys[0].tab;                            // one map size per launch
     const int16_t* tix = L.tab_idx + (size_t)tab * O * 4;
@@ -190,18 +220,18 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
         }
       }
     }
-    __syncthreads();                                           // red[] zeroed
-#pragma unroll
-    for (int oy = 0; oy < O; ++oy) {
-        float v;
-        if (P0 == 1 && oy == 0) v = edge[0];
-        else if (P0 == 1 && oy == O - 1) v = edge[1];
-        else v = acc2[(oy - P0) >> 1][(oy - P0) & 1];
-        atomicAdd(&red[oy * O + lane], v);                     // ds_add_f32
-    }
-    __syncthreads();
-    float* out = L.out + (size_t)tok * O * O;
-    for (int i = tid; i < O * O; i += 256) atomicAdd(out + i, red[i] * L.inv_n);
+    auto get = [&](int oy) -> float {
+        if (P0 == 1 && oy == 0) return edge[0];
+        if (P0 == 1 && oy == O - 1) return edge[1];
+        return acc2[(oy - P0) >> 1][(oy - P0) & 1];
+    };
+    auto add = [&](int oy, float v) {
+        if (P0 == 1 && oy == 0) edge[0] += v;
+        else if (P0 == 1 && oy == O - 1) edge[1] += v;
+        else acc2[(oy - P0) >> 1][(oy - P0) & 1] += v;
+    };
+    wg_reduce_flush(red, wave, get, add,
+                    [&](int i) { return i * O + lane; }, L.out + (size_t)tok * O * O, L.inv_n);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -233,12 +263,11 @@ __global__ __launch_bounds__(256) void finalize_up32_mfma_kernel(const FinLaunch
     constexpr int S = 32, O = 64;
     constexpr int kDepth = 4, kMaxKeysPerWave = 64;
     __shared__ const void* kbase[4][kMaxKeysPerWave];
-    __shared__ __align__(16) float red[O * O];
+    __shared__ __align__(16) float red[2 * O * O];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, g = lane >> 5;
     const int tok = blockIdx.x;
-    for (int i = tid; i < O * O; i += 256) red[i] = 0.f;
 
     const int tab = as_global<FinKey>(L.keys)[0].tab;
     const int16_t* tix = L.tab_idx + (size_t)tab * O * 4;
@@ -368,14 +397,11 @@ __global__ __launch_bounds__(256) void finalize_up32_mfma_kernel(const FinLaunch
         }
       }
     }
-    __syncthreads();                                           // red[] zeroed
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int i = 0; i < 32; ++i) atomicAdd(&red[(32 * g + i) * O + 32 * nt + n], acc[nt][i]);     // ds_add_f32
-    __syncthreads();
-    float* out = L.out + (size_t)tok * O * O;
-    for (int i = tid; i < O * O; i += 256) atomicAdd(out + i, red[i] * L.inv_n);
+    // element i = (tile i / 32, local row i % 32)  ->  out[32g + i % 32][32 (i / 32) + n]
+    wg_reduce_flush(red, wave, [&](int i) { return acc[i >> 5][i & 31]; },
+                    [&](int i, float v) { acc[i >> 5][i & 31] += v; },
+                    [&](int i) { return (32 * g + (i & 31)) * O + 32 * (i >> 5) + n; },
+                    L.out + (size_t)tok * O * O, L.inv_n);
 }
 
 // side == out_side: out[t][i] += sum over this chunk's keys of max(plane[t][i], 0) / N.
