@@ -190,7 +190,7 @@ def main():
     ap.add_argument('--defer', type=int, default=int(os.environ.get('DAAM_DEFER_STEPS', '8')),
                     help='denoising steps tapped per launch (0 = one launch per layer call)')
     ap.add_argument('--accumulate', default='exact', choices=['exact', 'float32'])
-    ap.add_argument('--pool', type=int, default=3, help='distinct synthetic Q/K step sets resident in HBM')
+    ap.add_argument('--pool', type=int, default=8, help='distinct synthetic Q/K step sets resident in HBM')
     ap.add_argument('--no-baselines', action='store_true', help='skip the CPU / eager-GPU reference timings')
     args = ap.parse_args()
 
@@ -275,7 +275,7 @@ def main():
                 traffic = rec.get('tap_bytes_per_launch') if rec else None
             except Exception:
                 traffic = None
-        roofline = dict(bound='hbm', kernel='tap_mfma_kernel<4,half>' if wl['kind'] == 'sdxl' else 'tap_mfma_kernel<*>',
+        roofline = dict(bound='hbm', kernel='tap_mfma_kernel<KS=4,fp16 sums>' if wl['kind'] == 'sdxl' else 'tap_mfma_kernel<KS=3|5|10>',
                         achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
                         traffic=traffic, bytes_per_launch=int(bytes_launch), ms_per_launch=round(tap_ms, 4),
                         steps_per_launch=spl, launches_per_generation=launches_per_gen,
@@ -299,7 +299,7 @@ def main():
             gpu_bound_maps_per_s=round(1e3 / gpu_ms_per_gen, 1),
             host_enqueue_ms_per_generation=round(host_ms, 3),
             raw_maps_per_s=round(world * args.steps * args.denoise_steps * sum(h for _, h, _, _ in layers) / elapsed, 1),
-            roofline_finalize=dict(bound='hbm', kernel='finalize_same_kernel + finalize_up_kernel<32>', achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
+            roofline_finalize=dict(bound='hbm', kernel='finalize_same_kernel + finalize_up32_mfma_kernel (+ memset)', achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
                                    unit='GB/s', frac=round(fin_gbs / HBM_PEAK_GBS, 4), bytes_per_launch=int(fin_bytes),
                                    ms_per_launch=round(fin_ms, 4)),
         )

@@ -635,8 +635,10 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             L.n_chunks = std::max(1, std::min(n, 32));
             e = launch_finalize(L, c->acc_dtype, s, &grid, &lds);
         } else {
-            // each wave takes keys first, first + 4*n_chunks, ...: at most 64 per wave
-            const int want = env_chunks ? env_chunks : 8;
+            // each wave takes keys first, first + 4*n_chunks, ...: at most 64 per wave.  ~1000 workgroups
+            // (two full rounds at 2 workgroups per CU) measured best: fewer leaves a ragged tail,
+            // more pays the per-workgroup reduction + atomics too often.
+            const int want = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
             L.n_chunks = std::max(std::max(1, std::min((n + 3) / 4, want)), (n + 255) / 256);
             e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, c->tab_fp16_exact[keys[cls][0].tab] && !c->no_mfma_finalize, s, &grid);
         }
