@@ -134,6 +134,8 @@ struct Layer {
     size_t bytes = 0;
     int tab = -1;
     bool dirty = false;      // tapped since the last reset (else the sums are known to be zero)
+    bool zero_pending = false;  // reset() was called but the buffer has not been cleared yet: the next
+                                // MFMA tap overwrites it (fresh), anything else clears it first
 };
 
 struct Pending {
@@ -190,6 +192,15 @@ static void bicubic_table(int in_size, int out_size, int16_t* idx, float* w)
             idx[j * 4 + a] = (int16_t)v;
         }
     }
+}
+
+static int ensure_zeroed(Layer& l, hipStream_t s)
+{
+    if (l.zero_pending) {
+        HIP_TRY(hipMemsetAsync(l.acc, 0, l.bytes, s));
+        l.zero_pending = false;
+    }
+    return 0;
 }
 
 extern "C" {
@@ -300,6 +311,10 @@ int daam_layer_acc(DaamCtx* c, int layer, void** acc, size_t* bytes)
 {
     if (!c || layer < 0 || layer >= c->max_layers || !c->layers[layer].configured)
         return fail(DAAM_E_STATE, "layer %d not configured", layer);
+    {
+        int zrc = ensure_zeroed(c->layers[layer], nullptr);
+        if (zrc) return zrc;
+    }
     if (acc) *acc = c->layers[layer].acc;
     if (bytes) *bytes = c->layers[layer].bytes;
     return 0;
@@ -309,9 +324,12 @@ int daam_reset(DaamCtx* c, void* stream)
 {
     if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
     c->drop_pending();
+    (void)stream;
     for (auto& l : c->layers)
         if (l.configured) {
-            HIP_TRY(hipMemsetAsync(l.acc, 0, l.bytes, (hipStream_t)stream));
+            // lazy: a layer that is tapped again is overwritten by its first launch (TapLayer.fresh),
+            // so the 221 MB of memsets per generation are only paid for paths that read the sums first
+            l.zero_pending = l.zero_pending || l.dirty;
             l.dirty = false;
         }
     return 0;
@@ -370,6 +388,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     if (rc) return rc;
     if (!c->pending.empty()) return fail(DAAM_E_STATE, "immediate tap with deferred taps pending: flush first");
     const bool mfma = use_mfma(c, *d, q, k);
+    if (!mfma && (rc = ensure_zeroed(c->layers[layer], (hipStream_t)stream))) return rc;
     TapLaunch L;
     memset(&L, 0, sizeof L);
     fill_layer(c, c->layers[layer], *d, mfma ? tap_mfma_tile_pixels() : kTapPixels, &L.one);
@@ -385,6 +404,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
                                              &c->last_grid[0], &c->last_lds[0]);
     if (e != hipSuccess) return fail((int)e, "tap launch: %s", hipGetErrorString(e));
     c->layers[layer].dirty = true;
+    c->layers[layer].zero_pending = false;
     return 0;
 }
 
@@ -478,6 +498,11 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         for (size_t i = 0; i < order.size(); ++i)
             if (kind[i] == kd) { ++n_layers; n_ptrs += per[i].size(); }
         const int tile = kd ? tap_mfma_tile_pixels() : kTapPixels;
+        if (!kd) {                                           // the generic kernel reads the sums first
+            for (size_t i = 0; i < order.size() && !rc; ++i)
+                if (kind[i] == kd) rc = ensure_zeroed(c->layers[order[i]], s);
+            if (rc) break;
+        }
         const size_t bytes_layers = n_layers * sizeof(TapLayer), bytes = bytes_layers + n_ptrs * sizeof(TapPtr);
         size_t off = 0;
         hipError_t e = c->ring.alloc(bytes, &off);
@@ -516,7 +541,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         e = c->ring.release(s);
         if (e != hipSuccess) { rc = fail((int)e, "event record: %s", hipGetErrorString(e)); break; }
         for (size_t i = 0; i < order.size(); ++i)
-            if (kind[i] == kd) c->layers[order[i]].dirty = true;
+            if (kind[i] == kd) { c->layers[order[i]].dirty = true; c->layers[order[i]].zero_pending = false; }
     }
     c->last_grid[0] = grid_total;
     c->last_block[0] = 256;
@@ -538,6 +563,10 @@ int daam_tap_probs(DaamCtx* c, int layer, const void* probs, int in_dtype, int b
     if (batch_heads - batch_heads / 2 != l.heads || hw != l.hw)
         return fail(DAAM_E_INVALID, "layer %d is [%d heads, %d positions], call has [%d kept, %d]", layer, l.heads, l.hw,
                     batch_heads - batch_heads / 2, hw);
+    {
+        int zrc = ensure_zeroed(c->layers[layer], (hipStream_t)stream);
+        if (zrc) return zrc;
+    }
     ProbsLaunch L;
     L.acc = l.acc;
     L.probs = probs;
@@ -572,6 +601,11 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
 {
     if (!c || !out) return fail(DAAM_E_INVALID, "NULL argument");
     if (!c->pending.empty()) return fail(DAAM_E_STATE, "finalize with deferred taps pending: flush first");
+    for (auto& l : c->layers)
+        if (l.configured) {
+            int zrc = ensure_zeroed(l, (hipStream_t)stream);
+            if (zrc) return zrc;
+        }
     // classes: 0 = same size (clamp + mean), 1 = x2 (32 -> 64), 2 = x4 (16 -> 64), 3 = general kernel
     std::vector<FinKey> keys[4];
     int pos = 0, max_side = 0, total = 0;

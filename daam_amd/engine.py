@@ -225,6 +225,8 @@ class HeatMapEngine:
         t, h, w = heat_map.shape
         if layer not in self.layer_info:
             raise RuntimeError('daam_amd: update() on a layer that was never tapped is not supported')
+        # clear() is lazy on the device side: make sure this layer's buffer really holds zeros / sums
+        nat.check(self.lib.daam_layer_acc(self.ctx, layer, None, None))
         self.acc[layer][head] += heat_map.to(self.acc_dtype)
         self._touch(layer)
 
