@@ -399,7 +399,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     L.total_wgs = L.one.heads_kept * L.one.tiles_per_head;
     L.wgs_per_xcd = (L.total_wgs + 7) / 8;
     c->last_block[0] = 256;
-    hipError_t e = mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+    hipError_t e = mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                         : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
                                              &c->last_grid[0], &c->last_lds[0]);
     if (e != hipSuccess) return fail((int)e, "tap launch: %s", hipGetErrorString(e));
@@ -509,7 +509,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         if (e != hipSuccess) { rc = fail((int)e, "upload ring: %s", hipGetErrorString(e)); break; }
         TapLayer* hl = reinterpret_cast<TapLayer*>(c->ring.host + off);
         TapPtr* hp = reinterpret_cast<TapPtr*>(c->ring.host + off + bytes_layers);
-        int wg = 0, ptr = 0, max_d = 0;
+        int wg = 0, ptr = 0, max_d = 0, all_round = 1;
         size_t j = 0;
         for (size_t i = 0; i < order.size(); ++i) {
             if (kind[i] != kd) continue;
@@ -521,6 +521,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             for (auto* p : v) { hp[ptr].q = p->q; hp[ptr].k = p->k; ++ptr; }
             wg += hl[j].heads_kept * hl[j].tiles_per_head;
             max_d = std::max(max_d, v[0]->d.head_dim);
+            all_round = all_round && v[0]->d.round_logits;
             ++j;
         }
         e = c->ring.commit(off, bytes, s);
@@ -534,7 +535,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         L.total_wgs = wg;
         L.wgs_per_xcd = (wg + 7) / 8;
         int grid = 0;
-        e = kd ? launch_tap_mfma(L, c->acc_dtype, max_d, c->fast_exp, s, &grid, &c->last_lds[0])
+        e = kd ? launch_tap_mfma(L, c->acc_dtype, max_d, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
                : launch_tap_generic(L, in_dtype, c->acc_dtype, max_d, s, &grid, &c->last_lds[0]);
         grid_total += grid;
         if (e != hipSuccess) { rc = fail((int)e, "tap launch: %s", hipGetErrorString(e)); break; }

@@ -26,6 +26,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 
 constexpr int kTok = 77;               // context_size (trace.py:194); the only value the reference taps
 constexpr int kTokRows = 96;           // 3 MFMA row tiles
@@ -62,12 +63,10 @@ constexpr float kMasked = -1.0e30f;    // logit of the padding tokens: exp() und
 
 // e^d for d <= 0 to ~1 ulp: 2^(d*log2e) on v_exp_f32 with the rounding error of the product
 // (and the low part of log2e) folded back in:  2^t * (1 + err * ln2).
-template <bool FAST>
 __device__ __forceinline__ float exp_nonpos(float d) {
     const float L = 1.44269502162933349609375f;       // log2(e) rounded to f32
     const float Llo = 1.92596303e-08f;                // log2(e) - L
     const float t = d * L;
-    if (FAST) return __builtin_amdgcn_exp2f(t);       // |rel err| <~ 1e-6 for d >= -17 (below: prob rounds to 0)
     float err = __builtin_fmaf(d, L, -t);
     err = __builtin_fmaf(d, Llo, err);
     const float r = __builtin_amdgcn_exp2f(t);
@@ -92,10 +91,15 @@ constexpr size_t tap_mfma_lds_bytes() {
 }
 
 // waves per SIMD the register allocator must leave room for: 4 for the fp16-sum SD/SDXL head dims
-template <int KS, typename ACC_T> constexpr int tap_mfma_min_waves() { return (KS <= 4 && sizeof(ACC_T) == 2) ? 4 : 2; }
+#ifndef DAAM_FAST_WAVES
+#define DAAM_FAST_WAVES 3
+#endif
+template <int KS, typename ACC_T, bool FAST> constexpr int tap_mfma_min_waves() {
+    return (KS <= 4 && sizeof(ACC_T) == 2) ? (FAST ? DAAM_FAST_WAVES : 4) : 2;
+}
 
 template <int KS, typename ACC_T, bool FAST_EXP>
-__global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T>())) void tap_mfma_kernel(const TapLaunch L)
+__global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T, FAST_EXP>())) void tap_mfma_kernel(const TapLaunch L)
 {
     constexpr int KROW = KS * 32 + 16;                        // bytes per K row in LDS
     constexpr int KBUF = kTokRows * KROW;                     // bytes per K buffer
@@ -229,6 +233,68 @@ __global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T>())) void tap_mf
         issue_k(nx);
         issue_q(nx);
 
+        if constexpr (FAST_EXP) {
+            // Fast softmax (host guarantees round_logits): logits stay packed fp16 (that IS their
+            // reference precision), max on v_pk_max_f16, exponent argument by ONE mixed-precision FMA
+            // t = x*log2(e) - m*log2(e) straight from the fp16 logit (v_fma_mix_f32), 2^t on v_exp_f32.
+            // The rounding of m*log2(e) is common to the 77 tokens of a pixel and cancels in e/sum; what
+            // remains (one f32 rounding of t, log2(e) to f32) is <~1e-6 relative, i.e. the same class of
+            // deviation as the f32 summation order of q.k (an occasional 1-ulp flip of an fp16 probability).
+            half2v xh[kSlots / 2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xh[i] = half2v{(_Float16)(c0[2 * i] * lay.scale), (_Float16)(c0[2 * i + 1] * lay.scale)};
+                xh[8 + i] = half2v{(_Float16)(c1[2 * i] * lay.scale), (_Float16)(c1[2 * i + 1] * lay.scale)};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xh[16 + i] = half2v{(_Float16)(c2[2 * i] * lay.scale), (_Float16)(c2[2 * i + 1] * lay.scale)};
+            if (g == 1) {                                                // tokens 77..79 of the upper lane half
+                const _Float16 ninf = -(_Float16)__builtin_inff();
+                xh[18][1] = ninf;
+                xh[19] = half2v{ninf, ninf};
+            }
+            half2v ma = xh[0], mb = xh[1];
+#pragma unroll
+            for (int i = 2; i < kSlots / 2; i += 2) {
+                ma = __builtin_elementwise_max(ma, xh[i]);
+                mb = __builtin_elementwise_max(mb, xh[i + 1]);
+            }
+            ma = __builtin_elementwise_max(ma, mb);
+            float m = fmaxf((float)ma[0], (float)ma[1]);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const float L = 1.44269502162933349609375f;
+            const float nmL = -m * L;
+            float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
+            float2v ev[kSlots / 2];
+#pragma unroll
+            for (int i = 0; i < kSlots / 2; i += 2) {
+                ev[i] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][0], L, nmL)),
+                                __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][1], L, nmL))};
+                ev[i + 1] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][0], L, nmL)),
+                                    __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][1], L, nmL))};
+                sa += ev[i];
+                sb += ev[i + 1];
+            }
+            sa += sb;
+            float sum = sa[0] + sa[1];
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int i = 0; i < kSlots / 2; ++i) {
+                const float2v p = ev[i] * inv;
+                const half2v ph = {(_Float16)p[0], (_Float16)p[1]};      // probs.to(dtype)
+                if constexpr (sizeof(ACC_T) == 2) {                      // heatmap.py:156, as v_pk_add_f16
+                    half2v r = {(_Float16)run[2 * i], (_Float16)run[2 * i + 1]};
+                    r += ph;
+                    run[2 * i] = (ACC_T)r[0];
+                    run[2 * i + 1] = (ACC_T)r[1];
+                } else {
+                    run[2 * i] = run[2 * i] + (ACC_T)ph[0];
+                    run[2 * i + 1] = run[2 * i + 1] + (ACC_T)ph[1];
+                }
+            }
+        } else {
         // logits: alpha in f32, then the baddbmm output rounding (skipped for upcast_attention)
         float x[kSlots];
 #pragma unroll
@@ -250,10 +316,10 @@ __global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T>())) void tap_mf
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int i = 0; i < kSlots; i += 4) {
-            x[i] = exp_nonpos<FAST_EXP>(x[i] - m);         s0 += x[i];
-            x[i + 1] = exp_nonpos<FAST_EXP>(x[i + 1] - m); s1 += x[i + 1];
-            x[i + 2] = exp_nonpos<FAST_EXP>(x[i + 2] - m); s2 += x[i + 2];
-            x[i + 3] = exp_nonpos<FAST_EXP>(x[i + 3] - m); s3 += x[i + 3];
+            x[i] = exp_nonpos(x[i] - m);         s0 += x[i];
+            x[i + 1] = exp_nonpos(x[i + 1] - m); s1 += x[i + 1];
+            x[i + 2] = exp_nonpos(x[i + 2] - m); s2 += x[i + 2];
+            x[i + 3] = exp_nonpos(x[i + 3] - m); s3 += x[i + 3];
         }
         float sum = (s0 + s1) + (s2 + s3);
         sum += __shfl_xor(sum, 32, 64);
@@ -262,6 +328,7 @@ __global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T>())) void tap_mf
         for (int i = 0; i < kSlots; ++i) {
             const _Float16 prob = (_Float16)(x[i] * inv);                // probs.to(dtype)
             run[i] = run[i] + (ACC_T)prob;                               // heatmap.py:156
+        }
         }
         commit_k((s + 1) & 1);
     }
