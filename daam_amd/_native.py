@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_void_p
 
 LIB_NAME = 'libdaam_hip.so'
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+LIB_PATH = os.environ.get('DAAM_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 DAAM_F16, DAAM_F32 = 0, 1
 E_INVALID, E_STATE, E_NOMAPS, E_UNSUPPORTED = -1, -2, -3, -4
