@@ -91,11 +91,11 @@ constexpr size_t tap_mfma_lds_bytes() {
 }
 
 // waves per SIMD the register allocator must leave room for: 4 for the fp16-sum SD/SDXL head dims
-#ifndef DAAM_TAP_WAVES
-#define DAAM_TAP_WAVES 3
+#ifndef DAAM_FAST_WAVES
+#define DAAM_FAST_WAVES 3
 #endif
 template <int KS, typename ACC_T, bool FAST> constexpr int tap_mfma_min_waves() {
-    return (KS <= 4 && sizeof(ACC_T) == 2) ? DAAM_TAP_WAVES : 2;
+    return (KS <= 4 && sizeof(ACC_T) == 2) ? (FAST ? DAAM_FAST_WAVES : 4) : 2;
 }
 
 template <int KS, typename ACC_T, bool FAST_EXP>
@@ -218,58 +218,21 @@ __global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T, FAST_EXP>())) v
     for (int s = 0; s < n_steps; ++s) {
         __syncthreads();
         const unsigned char* kb = kbuf + (s & 1) * KBUF;
-        // MFMA phase, one 32-token row tile at a time: the KS A-operand pieces of a tile are
-        // fetched from LDS together (one exposed LDS latency per tile instead of one per MFMA; the
-        // fast path also fetches the next tile's pieces ahead), and the tile's 16 f32 results are
-        // scaled / rounded to their reference precision immediately, so only one accumulator tile
-        // is live at a time.
-        constexpr bool kAhead = FAST_EXP && KS <= 5;
-        half8 at[kAhead ? 2 : 1][KS];
-        auto load_a = [&](int mt, int buf) {
+        floatx16 c0 = {0}, c1 = {0}, c2 = {0};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                at[buf][ks] = *reinterpret_cast<const half8*>(kb + (mt * 32 + n) * KROW + (2 * ks + g) * 16);
-        };
-        half2v xh[kSlots / 2];                                 // fast path: logits as packed fp16
-        float x[FAST_EXP ? 1 : kSlots];                        // strict path: logits as f32
-        load_a(0, 0);
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt) {
-            const int cur = kAhead ? (mt & 1) : 0;
-            if (kAhead && mt + 1 < 3) load_a(mt + 1, (mt + 1) & 1);
-            floatx16 c = {0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(at[cur][ks], bq[ks], c, 0, 0, 0);
-#if defined(DAAM_ABLATE) && DAAM_ABLATE == 2      // debug: no MFMA
-            c = floatx16{0}; c[0] = (float)bq[0][0];
-#endif
-            if (!kAhead && mt + 1 < 3) load_a(mt + 1, 0);
-            constexpr int kUsed[3] = {16, 16, 8};              // row tile 2 holds tokens 64..76 (+3 masked) in its first 8 slots
-            if constexpr (FAST_EXP) {
-#pragma unroll
-                for (int i = 0; i < kUsed[mt] / 2; ++i)
-                    xh[mt * 8 + i] = half2v{(_Float16)(c[2 * i] * lay.scale), (_Float16)(c[2 * i + 1] * lay.scale)};
-            } else {
-                // alpha in f32, then the baddbmm output rounding (skipped for upcast_attention)
-#pragma unroll
-                for (int i = 0; i < kUsed[mt]; ++i) {
-                    const float v = c[i] * lay.scale;
-                    x[mt * 16 + i] = lay.round_logits ? (float)(_Float16)v : v;
-                }
-            }
+        for (int ks = 0; ks < KS; ++ks) {
+            const int col = (2 * ks + g) * 16;
+            const half8 a0 = *reinterpret_cast<const half8*>(kb + (n) * KROW + col);
+            const half8 a1 = *reinterpret_cast<const half8*>(kb + (32 + n) * KROW + col);
+            const half8 a2 = *reinterpret_cast<const half8*>(kb + (64 + n) * KROW + col);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[ks], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[ks], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, bq[ks], c2, 0, 0, 0);
         }
         const int nx = min(s + 1, n_steps - 1);               // branch-free: the last step re-fetches itself
-#if !defined(DAAM_ABLATE) || (DAAM_ABLATE != 4 && DAAM_ABLATE != 5)
         issue_k(nx);
-#endif
-#if !defined(DAAM_ABLATE) || (DAAM_ABLATE != 3 && DAAM_ABLATE != 5)
         issue_q(nx);
-#endif
 
-#if defined(DAAM_ABLATE) && DAAM_ABLATE == 1      // debug: no softmax
-        run[0] = run[0] + (ACC_T)(FAST_EXP ? (float)xh[0][0] + (float)xh[9][1] + (float)xh[17][0] : x[0]);
-        if (false)
-#endif
         if constexpr (FAST_EXP) {
             // Fast softmax (host guarantees round_logits): logits stay packed fp16 (that IS their
             // reference precision), max on v_pk_max_f16, exponent argument by ONE mixed-precision FMA
@@ -277,6 +240,15 @@ __global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T, FAST_EXP>())) v
             // The rounding of m*log2(e) is common to the 77 tokens of a pixel and cancels in e/sum; what
             // remains (one f32 rounding of t, log2(e) to f32) is <~1e-6 relative, i.e. the same class of
             // deviation as the f32 summation order of q.k (an occasional 1-ulp flip of an fp16 probability).
+            half2v xh[kSlots / 2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xh[i] = half2v{(_Float16)(c0[2 * i] * lay.scale), (_Float16)(c0[2 * i + 1] * lay.scale)};
+                xh[8 + i] = half2v{(_Float16)(c1[2 * i] * lay.scale), (_Float16)(c1[2 * i + 1] * lay.scale)};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xh[16 + i] = half2v{(_Float16)(c2[2 * i] * lay.scale), (_Float16)(c2[2 * i + 1] * lay.scale)};
             if (g == 1) {                                                // tokens 77..79 of the upper lane half
                 const _Float16 ninf = -(_Float16)__builtin_inff();
                 xh[18][1] = ninf;
@@ -323,6 +295,16 @@ __global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T, FAST_EXP>())) v
                 }
             }
         } else {
+        // logits: alpha in f32, then the baddbmm output rounding (skipped for upcast_attention)
+        float x[kSlots];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { x[i] = c0[i] * lay.scale; x[16 + i] = c1[i] * lay.scale; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[32 + i] = c2[i] * lay.scale;
+        if (lay.round_logits) {
+#pragma unroll
+            for (int i = 0; i < kSlots; ++i) x[i] = (float)(_Float16)x[i];
+        }
         if (g == 1) { x[37] = kMasked; x[38] = kMasked; x[39] = kMasked; }   // tokens 77..79 of the upper lane half
         float m0 = x[0], m1 = x[1], m2 = x[2], m3 = x[3];
 #pragma unroll
