@@ -22,6 +22,9 @@ bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t 
 int tap_mfma_tile_pixels();
 int tap_mfma_ksteps(int head_dim);
 int tap_mfma_max_steps();
+hipError_t launch_tap_mfma64(const TapLaunch&, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
+bool tap_mfma64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb,
+                          int64_t k_sh, const void* q, const void* k);
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
 hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
@@ -165,6 +168,7 @@ struct DaamCtx {
     int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
     int force_generic = 0;
     int fast_exp = 0;
+    int no_dma = 0;
 };
 
 static size_t acc_elem(int dtype) { return dtype == DAAM_F16 ? 2 : 4; }
@@ -236,6 +240,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->force_generic = fg && fg[0] == '1';
     const char* nm = getenv("DAAM_NO_MFMA_FINALIZE");
     c->no_mfma_finalize = nm && nm[0] == '1';
+    const char* nd = getenv("DAAM_NO_DMA");
+    c->no_dma = nd && nd[0] == '1';
     const char* fe = getenv("DAAM_FAST_EXP");
     c->fast_exp = fe && fe[0] == '1';
     *out = c;
@@ -382,6 +388,12 @@ static bool use_mfma(const DaamCtx* c, const DaamQKDesc& d, const void* q, const
                               d.q_stride_h, d.k_stride_b, d.k_stride_h);
 }
 
+static bool use_mfma64(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
+{
+    return !c->no_dma && tap_mfma64_supported(d.head_dim, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h,
+                                              d.k_stride_b, d.k_stride_h, q, k);
+}
+
 int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQKDesc* d, void* stream)
 {
     int rc = check_qk(c, layer, q, k, d);
@@ -399,7 +411,9 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     L.total_wgs = L.one.heads_kept * L.one.tiles_per_head;
     L.wgs_per_xcd = (L.total_wgs + 7) / 8;
     c->last_block[0] = 256;
-    hipError_t e = mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+    hipError_t e = (mfma && use_mfma64(c, *d, q, k))
+                       ? launch_tap_mfma64(L, c->acc_dtype, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+                   : mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                         : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
                                              &c->last_grid[0], &c->last_lds[0]);
     if (e != hipSuccess) return fail((int)e, "tap launch: %s", hipGetErrorString(e));
@@ -486,6 +500,8 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         }
         const int i = slot[p.layer];
         if (!use_mfma(c, p.d, p.q, p.k)) kind[i] = 0;
+        else if (kind[i] == 4 && per[i].empty() && use_mfma64(c, p.d, p.q, p.k)) kind[i] = 64;   // DMA kernel
+        else if (kind[i] == 64 && !use_mfma64(c, p.d, p.q, p.k)) kind[i] = 4;
         per[i].push_back(&p);
     }
     std::vector<int> kinds;
@@ -535,7 +551,8 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         L.total_wgs = wg;
         L.wgs_per_xcd = (wg + 7) / 8;
         int grid = 0;
-        e = kd ? launch_tap_mfma(L, c->acc_dtype, max_d, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
+        e = kd == 64 ? launch_tap_mfma64(L, c->acc_dtype, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
+          : kd ? launch_tap_mfma(L, c->acc_dtype, max_d, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
                : launch_tap_generic(L, in_dtype, c->acc_dtype, max_d, s, &grid, &c->last_lds[0]);
         grid_total += grid;
         if (e != hipSuccess) { rc = fail((int)e, "tap launch: %s", hipGetErrorString(e)); break; }

@@ -34,7 +34,7 @@ class HeatMapEngine:
         self.tokens = int(tokens)
         self.out_side = int(out_side)
         self.accumulate = accumulate
-        self.defer_steps = int(defer_steps)
+        self.defer_steps = min(int(defer_steps), 64)     # the kernels stage at most 64 steps of pointers per launch
         self.ctx: Optional[nat.c_void_p] = None
         self.device: Optional[torch.device] = None
         self.acc_dtype: Optional[torch.dtype] = None
