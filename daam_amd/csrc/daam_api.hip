@@ -240,8 +240,10 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->force_generic = fg && fg[0] == '1';
     const char* nm = getenv("DAAM_NO_MFMA_FINALIZE");
     c->no_mfma_finalize = nm && nm[0] == '1';
-    const char* nd = getenv("DAAM_NO_DMA");
-    c->no_dma = nd && nd[0] == '1';
+    // the LDS-DMA operand kernel (head_dim 64) is correct but measured 10 % slower than the register
+    // path on MI355X (round 1): opt-in for experiments
+    const char* nd = getenv("DAAM_DMA");
+    c->no_dma = !(nd && nd[0] == '1');
     const char* fe = getenv("DAAM_FAST_EXP");
     c->fast_exp = fe && fe[0] == '1';
     *out = c;

@@ -256,6 +256,33 @@ def test_trace_api_matches_reference_golden(golden_case, tap, defer):
     assert out.images
 
 
+@pytest.mark.parametrize('env', [dict(DAAM_FAST_EXP='1'), dict(DAAM_DMA='1'), dict(DAAM_DMA='1', DAAM_FAST_EXP='1'),
+                                 dict(DAAM_FORCE_GENERIC='1')])
+def test_optional_kernel_paths_keep_parity(env, monkeypatch):
+    """The opt-in / fallback kernel variants (fast softmax, LDS-DMA operands for head_dim 64, the
+    any-shape kernels) stay within the same tolerances on an SDXL-shaped fp16 case (head_dim 64)."""
+    import daam_amd
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    from oracle import fake_diffusers as fd
+    steps, prompt = 4, 'a photo of a monkey'
+    kw = dict(dtype=torch.float16, batch=2, seed=21, mini=True, identity_proj=True, dim_head=64, heads_scale=0.1,
+              tblocks_cap=1)
+    pipe = fd.make_pipe('sdxl', device=DEV, **kw)
+    with daam_amd.trace(pipe, defer_steps=3) as tc:
+        pipe(prompt, num_inference_steps=steps)
+        got_raw = {k: v.float().cpu().numpy() for k, v in tc.all_heat_maps}
+        got = tc.compute_global_heat_map().heat_maps.cpu().numpy()
+    cpu_pipe = fd.make_pipe('sdxl', device='cpu', **kw)
+    raw = ho.replay_generation(cpu_pipe, steps, torch.float16)
+    assert [k for k, _ in raw] == list(got_raw)
+    for k, v in raw:
+        assert np.abs(got_raw[k] - v.astype(np.float32)).max() <= 2.0 ** -10 * max(1.0, float(v.max()))
+    lat = ho.latent_hw_for(cpu_pipe.unet.config.sample_size, cpu_pipe.vae_scale_factor)
+    want = ho.global_heat_map(raw, lat, n_rows=len(cpu_pipe.tokenizer.tokenize(prompt)) + 2)
+    assert np.abs(got - want).max() <= 1e-3
+
+
 def test_trace_errors_and_reset():
     import daam_amd
     z, meta = load_golden('sd15_f16')
@@ -326,5 +353,7 @@ def test_full_size_layer_properties(heads, side, d):
     kc[:] = kc[:, :1]                                            # all keys identical -> uniform attention
     eng.tap_qk(0, qs[0], kc, heads, d ** -0.5, factor=1)
     acc = torch.stack([v for _, v in eng.items()]).float()
-    assert (acc - float(np.float16(1.0 / 77))).abs().max().item() == 0.0
+    import os
+    exact = os.environ.get('DAAM_FAST_EXP', '0') != '1'       # the fast softmax may be one fp16 ulp off here
+    assert (acc - float(np.float16(1.0 / 77))).abs().max().item() <= (0.0 if exact else 2.0 ** -17)
     eng.close()
