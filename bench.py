@@ -72,12 +72,19 @@ def make_inputs(layers, pool, device, seed):
     return sets
 
 
-def one_generation(eng, layers, sets, denoise_steps, latent_side):
+def call_lists(layers, sets, latent_side):
+    """Per step set: the argument tuples of the per-layer processor calls, in UNet execution order."""
+    return [[(layer, q, k, heads, d ** -0.5, (latent_side // side) if side <= latent_side else 0)
+             for (layer, heads, side, d), (q, k) in zip(layers, cur)] for cur in sets]
+
+
+def one_generation(eng, calls, denoise_steps):
     eng.clear()
+    tap = eng.tap_qk
+    n = len(calls)
     for t in range(denoise_steps):
-        cur = sets[t % len(sets)]
-        for (layer, heads, side, d), (q, k) in zip(layers, cur):
-            eng.tap_qk(layer, q, k, heads, d ** -0.5, factor=max(0, latent_side // side) if side <= latent_side else 0)
+        for a in calls[t % n]:
+            tap(*a)
     eng.flush()
     return eng.global_heat_map()
 
@@ -90,7 +97,7 @@ def tap_bytes(layers, steps_per_launch, acc_bytes, fresh):
     return steps_per_launch * qk + acc * (1 if fresh else 2), qk, acc
 
 
-def measure_tap_kernel(eng, layers, sets, defer, latent_side, reps):
+def measure_tap_kernel(eng, calls, defer, reps):
     """HIP-event time of back-to-back tap launches (all Q/K pointers recorded first, so the
     stream sees table upload + kernel only)."""
     stream = torch.cuda.current_stream()
@@ -98,9 +105,8 @@ def measure_tap_kernel(eng, layers, sets, defer, latent_side, reps):
     times = []
     for r in range(reps + 2):
         for s in range(defer):
-            cur = sets[(r * defer + s) % len(sets)]
-            for (layer, heads, side, d), (q, k) in zip(layers, cur):
-                eng.tap_qk(layer, q, k, heads, d ** -0.5, factor=max(0, latent_side // side) if side <= latent_side else 0)
+            for a in calls[(r * defer + s) % len(calls)]:
+                eng.tap_qk(*a)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         eng.flush()
@@ -187,7 +193,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='sdxl1024', choices=sorted(WORKLOADS))
     ap.add_argument('--denoise-steps', type=int, default=50)
-    ap.add_argument('--defer', type=int, default=int(os.environ.get('DAAM_DEFER_STEPS', '8')),
+    ap.add_argument('--defer', type=int, default=int(os.environ.get('DAAM_DEFER_STEPS', '16')),
                     help='denoising steps tapped per launch (0 = one launch per layer call)')
     ap.add_argument('--accumulate', default='exact', choices=['exact', 'float32'])
     ap.add_argument('--pool', type=int, default=8, help='distinct synthetic Q/K step sets resident in HBM')
@@ -216,8 +222,9 @@ def main():
     sets = make_inputs(layers, args.pool, device, seed=1234 + rank)
     eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=args.accumulate, defer_steps=args.defer)
 
+    calls = call_lists(layers, sets, latent_side)
     for _ in range(args.warmup):
-        one_generation(eng, layers, sets, args.denoise_steps, latent_side)
+        one_generation(eng, calls, args.denoise_steps)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -225,7 +232,7 @@ def main():
     results = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        results.append(one_generation(eng, layers, sets, args.denoise_steps, latent_side))
+        results.append(one_generation(eng, calls, args.denoise_steps))
     mine = torch.stack(results)
     if dist:
         gathered = torch.empty(world * args.steps, *mine.shape[1:], device=device, dtype=mine.dtype)
@@ -246,19 +253,19 @@ def main():
         spl = max(1, args.defer)
         # ---- roofline of the dominant kernel (tap) ---------------------------------------------
         if args.defer > 0:
-            tap_ms = measure_tap_kernel(eng, layers, sets, args.defer, latent_side, reps=10)
+            tap_ms = measure_tap_kernel(eng, calls, args.defer, reps=10)
             bytes_launch, qk_bytes, acc_total = tap_bytes(layers, spl, acc_bytes, fresh=False)
             launches_per_gen = -(-args.denoise_steps // spl)
         else:
             # immediate mode: 1 launch per layer call; time a whole denoising step of launches
             stream = torch.cuda.current_stream()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            one_generation(eng, layers, sets, 2, latent_side)
+            one_generation(eng, calls, 2)
             e0.record(stream)
             reps = 10
             for r in range(reps):
-                for (layer, heads, side, d), (q, k) in zip(layers, sets[r % len(sets)]):
-                    eng.tap_qk(layer, q, k, heads, d ** -0.5, factor=1)
+                for a in calls[r % len(calls)]:
+                    eng.tap_qk(*a)
             e1.record(stream)
             e1.synchronize()
             tap_ms = e0.elapsed_time(e1) / reps / len(layers)
@@ -284,8 +291,8 @@ def main():
         torch.cuda.synchronize()
         th0 = time.perf_counter()
         for t in range(args.denoise_steps):
-            for (layer, heads, side, d), (q, k) in zip(layers, sets[t % len(sets)]):
-                eng.tap_qk(layer, q, k, heads, d ** -0.5, factor=max(0, latent_side // side) if side <= latent_side else 0)
+            for a in calls[t % len(calls)]:
+                eng.tap_qk(*a)
         eng.flush()
         host_ms = (time.perf_counter() - th0) * 1e3
         torch.cuda.synchronize()

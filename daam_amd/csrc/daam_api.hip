@@ -244,8 +244,12 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     // path on MI355X (round 1): opt-in for experiments
     const char* nd = getenv("DAAM_DMA");
     c->no_dma = !(nd && nd[0] == '1');
+    // softmax flavour of the MFMA tap: fast (default; exponent by one mixed-precision FMA, ~1e-6 relative,
+    // same deviation class as the f32 summation order of q.k -- DESIGN.md section 3.1) or compensated
+    // (DAAM_STRICT_EXP=1 / DAAM_FAST_EXP=0: ~1 ulp f32 like the reference's expf)
     const char* fe = getenv("DAAM_FAST_EXP");
-    c->fast_exp = fe && fe[0] == '1';
+    const char* se = getenv("DAAM_STRICT_EXP");
+    c->fast_exp = !((se && se[0] == '1') || (fe && fe[0] == '0'));
     *out = c;
     return 0;
 }

@@ -42,13 +42,10 @@ class HeatMapEngine:
         self.layer_info: Dict[int, Tuple[int, int, int]] = {}   # layer -> (factor, heads, side)
         self.touched: List[int] = []                     # layers updated since clear(), first-update order
         # deferred taps: recorded per call (the tensors are kept alive until the flush)
-        self._rec_layer: List[int] = []
-        self._rec_q: List[torch.Tensor] = []
-        self._rec_k: List[torch.Tensor] = []
-        self._rec_desc: List[int] = []
-        self._pending: Dict[int, int] = {}
-        self._qk_cache: Dict[int, tuple] = {}
-        self._touched_set = set()
+        self._rec: List[tuple] = []                      # (layer, query, key, address of its DaamQKDesc)
+        self._cnt: List[int] = [0] * self.n_layers      # recorded steps per layer
+        self._qk_cache: List[Optional[tuple]] = [None] * self.n_layers
+        self._touched_flag: List[bool] = [False] * self.n_layers
 
     # ---- lifetime --------------------------------------------------------------------------
     def _require_device(self, t: torch.Tensor) -> None:
@@ -81,8 +78,8 @@ class HeatMapEngine:
         self.acc.clear()
         self.layer_info.clear()
         self.touched.clear()
-        self._touched_set.clear()
-        self._qk_cache.clear()
+        self._touched_flag = [False] * self.n_layers
+        self._qk_cache = [None] * self.n_layers
         self._drop_recorded()
 
     def __del__(self):
@@ -108,15 +105,15 @@ class HeatMapEngine:
         self.layer_info[layer] = (factor, heads, side)
 
     def _touch(self, layer: int) -> None:
-        if layer not in self._touched_set:
-            self._touched_set.add(layer)
+        if not self._touched_flag[layer]:
+            self._touched_flag[layer] = True
             self.touched.append(layer)
 
     # ---- RawHeatMapCollection.clear (heatmap.py:170-172) -----------------------------------------
     def clear(self) -> None:
         self._drop_recorded()
         self.touched.clear()
-        self._touched_set.clear()
+        self._touched_flag = [False] * self.n_layers
         if self.ctx is not None:
             nat.check(self.lib.daam_reset(self.ctx, self.stream))
 
@@ -125,35 +122,43 @@ class HeatMapEngine:
                factor: int, round_logits: bool = True) -> None:
         """``query`` [B, hw, heads*d], ``key`` [B, tokens, heads*d] straight out of ``to_q`` /
         ``to_k`` (trace.py:262,269); no ``head_to_batch_dim`` copy is made."""
-        c = self._qk_cache.get(layer)
-        if (c is None or c[0] != query.shape or c[1] != key.shape or c[2] is not query.dtype or c[3] != heads
-                or c[4] != scale or c[5] != round_logits or c[6] != factor or key.dtype is not query.dtype):
-            c = self._prepare_qk(layer, query, key, heads, scale, factor, round_logits)
-        if not query.is_contiguous():
-            query = query.contiguous()
-        if not key.is_contiguous():
-            key = key.contiguous()
-        if self.defer_steps > 0:
+        # Hot path (3000 calls per SDXL generation).  Full validation (shapes, dtypes, call parameters)
+        # runs on a layer's first call of every launch window; inside a window only the invariants
+        # that could silently change the memory layout are re-checked (element counts, dtype,
+        # contiguity) -- every torch attribute access costs 50-100 ns here.
+        c = self._qk_cache[layer]
+        cnt = self._cnt
+        if (c is None or cnt[layer] == 0 or not self.defer_steps):
+            if (c is None or c[0] != query.shape or c[1] != key.shape or c[2] is not query.dtype
+                    or key.dtype is not c[2] or c[3] != heads or c[4] != scale or c[5] != round_logits
+                    or c[6] != factor or not query.is_contiguous() or not key.is_contiguous()):
+                query, key, c = self._prepare_qk(layer, query, key, heads, scale, factor, round_logits)
+        elif (query.numel() != c[10] or key.numel() != c[11] or query.dtype is not c[2] or c[4] != scale
+              or not query.is_contiguous() or not key.is_contiguous()):
+            query, key, c = self._prepare_qk(layer, query, key, heads, scale, factor, round_logits)
+        if self.defer_steps:
             # record only: pointers cross the FFI in one daam_tap_qk_enqueue_many call per flush
-            n = self._pending.get(layer, 0)
+            n = cnt[layer]
             if n >= self.defer_steps:
                 self.flush()
                 n = 0
-            self._pending[layer] = n + 1
-            self._rec_layer.append(layer)
-            self._rec_q.append(query)
-            self._rec_k.append(key)
-            self._rec_desc.append(c[9])
+            cnt[layer] = n + 1
+            self._rec.append((layer, query, key, c[9]))
         else:
             rc = self.lib.daam_tap_qk(self.ctx, layer, query.data_ptr(), key.data_ptr(), c[7], self.stream)
             if rc:
                 nat.check(rc)
-        if layer not in self._touched_set:
+        if not self._touched_flag[layer]:
             self._touch(layer)
 
     def _prepare_qk(self, layer, query, key, heads, scale, factor, round_logits):
-        """Slow path of ``tap_qk``: validate, (re)configure the layer, build the call descriptor."""
+        """Slow path of ``tap_qk``: validate, (re)configure the layer, build the call descriptor.
+        Returns ``(query, key, cache entry)`` with both tensors contiguous."""
+        if not 0 <= layer < self.n_layers:
+            raise IndexError(f'layer {layer} out of range (trace has {self.n_layers} layers)')
         self._require_device(query)
+        query = query if query.is_contiguous() else query.contiguous()
+        key = key if key.is_contiguous() else key.contiguous()
         self._ensure_ctx(query.dtype)
         if query.dtype != key.dtype:
             raise RuntimeError('daam_amd: query / key dtype mismatch')
@@ -172,23 +177,24 @@ class HeatMapEngine:
             q_stride_b=hw * c, q_stride_h=d, q_stride_p=c,
             k_stride_b=tokens * c, k_stride_h=d, k_stride_t=c)
         # a shape change of a layer inside a deferred batch starts a new batch (the C side checks too)
-        if self._pending.get(layer, 0):
+        if self._cnt[layer]:
             self.flush()
         entry = (query.shape, key.shape, query.dtype, heads, scale, round_logits, factor, nat.byref(desc), desc,
-                 ctypes.addressof(desc))
+                 ctypes.addressof(desc), query.numel(), key.numel())
         self._qk_cache[layer] = entry
-        return entry
+        return query, key, entry
 
     def flush(self) -> None:
         """Run every recorded (deferred) tap; the held Q/K references are dropped afterwards
         (stream order keeps their memory valid until the kernel has consumed it)."""
-        n = len(self._rec_layer)
+        rec = self._rec
+        n = len(rec)
         if self.ctx is None or n == 0:
             return
-        layers = np.asarray(self._rec_layer, dtype=np.int32)
-        qp = np.fromiter((t.data_ptr() for t in self._rec_q), dtype=np.uint64, count=n)
-        kp = np.fromiter((t.data_ptr() for t in self._rec_k), dtype=np.uint64, count=n)
-        dp = np.asarray(self._rec_desc, dtype=np.uint64)
+        layers = np.fromiter((r[0] for r in rec), dtype=np.int32, count=n)
+        qp = np.fromiter((r[1].data_ptr() for r in rec), dtype=np.uint64, count=n)
+        kp = np.fromiter((r[2].data_ptr() for r in rec), dtype=np.uint64, count=n)
+        dp = np.fromiter((r[3] for r in rec), dtype=np.uint64, count=n)
         try:
             nat.check(self.lib.daam_tap_qk_enqueue_many(self.ctx, n, layers.ctypes.data, qp.ctypes.data, kp.ctypes.data,
                                                         dp.ctypes.data))
@@ -197,11 +203,8 @@ class HeatMapEngine:
             self._drop_recorded()
 
     def _drop_recorded(self) -> None:
-        self._rec_layer.clear()
-        self._rec_q.clear()
-        self._rec_k.clear()
-        self._rec_desc.clear()
-        self._pending.clear()
+        self._rec.clear()
+        self._cnt[:] = [0] * self.n_layers              # in place: tap_qk holds a reference across flush()
 
     def tap_probs(self, layer: int, probs: torch.Tensor, factor: int) -> None:
         """``probs`` [B*H, hw, tokens] as returned by ``get_attention_scores`` (trace.py:276)."""

@@ -30,7 +30,7 @@ __all__ = ['trace', 'DiffusionHeatMapHooker', 'GlobalHeatMap']
 
 
 def _default_defer() -> int:
-    return int(os.environ.get('DAAM_DEFER_STEPS', '8'))
+    return int(os.environ.get('DAAM_DEFER_STEPS', '16'))
 
 
 class DiffusionHeatMapHooker(AggregateHooker):
@@ -41,7 +41,7 @@ class DiffusionHeatMapHooker(AggregateHooker):
         ``accumulate`` = ``'exact'`` (running sums in the pipeline dtype, like the reference) or
         ``'float32'``; ``tap`` = ``'qk'`` (fused, default) or ``'probs'`` (materialised
         probabilities, bit-identical adds); ``defer_steps`` = denoising steps tapped per launch
-        (0 = one launch per layer call; default ``$DAAM_DEFER_STEPS`` or 8)."""
+        (0 = one launch per layer call; default ``$DAAM_DEFER_STEPS`` or 16; at most 64)."""
         if tap not in ('qk', 'probs'):
             raise ValueError("tap must be 'qk' or 'probs'")
         h = pipeline.unet.config.sample_size * pipeline.vae_scale_factor

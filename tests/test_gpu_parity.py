@@ -97,6 +97,7 @@ def test_tap_qk_vs_oracle(shape, mode, defer):
 
 def test_generic_and_mfma_agree(monkeypatch):
     """The baseline (any-shape) kernel and the MFMA kernel implement the same rounding points."""
+    monkeypatch.setenv('DAAM_STRICT_EXP', '1')
     rng = np.random.default_rng(7)
     q, k = _qk(rng, 2, 2, 1024, 64, np.float16)
     outs = []
@@ -256,10 +257,10 @@ def test_trace_api_matches_reference_golden(golden_case, tap, defer):
     assert out.images
 
 
-@pytest.mark.parametrize('env', [dict(DAAM_FAST_EXP='1'), dict(DAAM_DMA='1'), dict(DAAM_DMA='1', DAAM_FAST_EXP='1'),
+@pytest.mark.parametrize('env', [dict(DAAM_STRICT_EXP='1'), dict(DAAM_DMA='1'), dict(DAAM_DMA='1', DAAM_STRICT_EXP='1'),
                                  dict(DAAM_FORCE_GENERIC='1')])
 def test_optional_kernel_paths_keep_parity(env, monkeypatch):
-    """The opt-in / fallback kernel variants (fast softmax, LDS-DMA operands for head_dim 64, the
+    """The opt-in / fallback kernel variants (compensated-exp softmax, LDS-DMA operands for head_dim 64, the
     any-shape kernels) stay within the same tolerances on an SDXL-shaped fp16 case (head_dim 64)."""
     import daam_amd
     for k, v in env.items():
@@ -354,6 +355,6 @@ def test_full_size_layer_properties(heads, side, d):
     eng.tap_qk(0, qs[0], kc, heads, d ** -0.5, factor=1)
     acc = torch.stack([v for _, v in eng.items()]).float()
     import os
-    exact = os.environ.get('DAAM_FAST_EXP', '0') != '1'       # the fast softmax may be one fp16 ulp off here
+    exact = os.environ.get('DAAM_STRICT_EXP', '0') == '1'      # the default (fast) softmax may be one fp16 ulp off here
     assert (acc - float(np.float16(1.0 / 77))).abs().max().item() <= (0.0 if exact else 2.0 ** -17)
     eng.close()

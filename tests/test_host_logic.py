@@ -204,17 +204,17 @@ def test_engine_deferred_bookkeeping(fake_engine):
     assert lib.names().count('daam_tap_flush') == 2
     many = [c for c in lib.calls if c[0] == 'daam_tap_qk_enqueue_many']
     assert [c[1][1] for c in many] == [6, 6]
-    assert len(eng._rec_layer) == 3 and eng.touched == [2, 0, 1]
+    assert len(eng._rec) == 3 and eng.touched == [2, 0, 1]
     assert eng.keys()[:2] == [(1, 2, 0), (1, 2, 1)]
     list(eng.items())                                  # reading the sums flushes the rest
-    assert lib.names().count('daam_tap_flush') == 3 and not eng._rec_layer
+    assert lib.names().count('daam_tap_flush') == 3 and not eng._rec
     assert lib.names().count('daam_layer_configure') == 3
     # a shape change of a layer mid-batch starts a new batch and a new buffer
     eng.tap_qk(0, q[0], k[0], 2, 0.35, 1)
     eng.tap_qk(0, torch.zeros(2, 256, 16, dtype=torch.float16), k[0], 2, 0.35, 1)
     assert lib.names().count('daam_tap_flush') == 4 and lib.names().count('daam_layer_configure') == 4
     eng.clear()                                        # RawHeatMapCollection.clear: drop recorded taps, zero sums
-    assert not eng._rec_layer and not eng.touched and lib.names()[-1] == 'daam_reset'
+    assert not eng._rec and not eng.touched and lib.names()[-1] == 'daam_reset'
     with pytest.raises(LookupError):
         eng.global_heat_map()
     eng.close()
