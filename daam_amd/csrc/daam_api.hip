@@ -23,6 +23,9 @@ int tap_mfma_tile_pixels();
 int tap_mfma_ksteps(int head_dim);
 int tap_mfma_max_steps();
 hipError_t launch_tap_mfma64(const TapLaunch&, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
+hipError_t launch_tap_d64(const TapLaunch&, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
+bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+                       const void* q, const void* k);
 bool tap_mfma64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb,
                           int64_t k_sh, const void* q, const void* k);
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
@@ -169,6 +172,7 @@ struct DaamCtx {
     int force_generic = 0;
     int fast_exp = 0;
     int no_dma = 0;
+    int no_d64 = 0;
 };
 
 static size_t acc_elem(int dtype) { return dtype == DAAM_F16 ? 2 : 4; }
@@ -242,6 +246,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->no_mfma_finalize = nm && nm[0] == '1';
     // the LDS-DMA operand kernel (head_dim 64) is correct but measured 10 % slower than the register
     // path on MI355X (round 1): opt-in for experiments
+    const char* n16 = getenv("DAAM_NO_D64");
+    c->no_d64 = n16 && n16[0] == '1';
     const char* nd = getenv("DAAM_DMA");
     c->no_dma = !(nd && nd[0] == '1');
     // softmax flavour of the MFMA tap: fast (default; exponent by one mixed-precision FMA, ~1e-6 relative,
@@ -394,10 +400,27 @@ static bool use_mfma(const DaamCtx* c, const DaamQKDesc& d, const void* q, const
                               d.q_stride_h, d.k_stride_b, d.k_stride_h);
 }
 
+// kernel choice for an MFMA-capable call: 65 = 16x16-tile head_dim-64 kernel (default for d = 64),
+// 64 = LDS-DMA variant (opt-in), else the k-step count of the generic MFMA kernel
+static int mfma_kind(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k);
+
+static bool use_d64(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
+{
+    return !c->no_d64 && tap_d64_supported(d.head_dim, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h,
+                                           d.k_stride_b, d.k_stride_h, q, k);
+}
+
 static bool use_mfma64(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
     return !c->no_dma && tap_mfma64_supported(d.head_dim, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h,
                                               d.k_stride_b, d.k_stride_h, q, k);
+}
+
+static int mfma_kind(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
+{
+    if (use_mfma64(c, d, q, k)) return 64;
+    if (use_d64(c, d, q, k)) return 65;
+    return tap_mfma_ksteps(d.head_dim);
 }
 
 int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQKDesc* d, void* stream)
@@ -417,8 +440,9 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     L.total_wgs = L.one.heads_kept * L.one.tiles_per_head;
     L.wgs_per_xcd = (L.total_wgs + 7) / 8;
     c->last_block[0] = 256;
-    hipError_t e = (mfma && use_mfma64(c, *d, q, k))
-                       ? launch_tap_mfma64(L, c->acc_dtype, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+    const int kd1 = mfma ? mfma_kind(c, *d, q, k) : 0;
+    hipError_t e = kd1 == 64 ? launch_tap_mfma64(L, c->acc_dtype, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+                   : kd1 == 65 ? launch_tap_d64(L, c->acc_dtype, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                         : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
                                              &c->last_grid[0], &c->last_lds[0]);
@@ -506,8 +530,12 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         }
         const int i = slot[p.layer];
         if (!use_mfma(c, p.d, p.q, p.k)) kind[i] = 0;
-        else if (kind[i] == 4 && per[i].empty() && use_mfma64(c, p.d, p.q, p.k)) kind[i] = 64;   // DMA kernel
-        else if (kind[i] == 64 && !use_mfma64(c, p.d, p.q, p.k)) kind[i] = 4;
+        else if (kind[i] != 0) {
+            // every step of the layer must qualify for the specialised kernel, else the generic MFMA one
+            const int want = mfma_kind(c, p.d, p.q, p.k);
+            if (per[i].empty()) kind[i] = want;
+            else if (kind[i] != want) kind[i] = tap_mfma_ksteps(p.d.head_dim);
+        }
         per[i].push_back(&p);
     }
     std::vector<int> kinds;
@@ -558,6 +586,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         L.wgs_per_xcd = (wg + 7) / 8;
         int grid = 0;
         e = kd == 64 ? launch_tap_mfma64(L, c->acc_dtype, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
+          : kd == 65 ? launch_tap_d64(L, c->acc_dtype, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
           : kd ? launch_tap_mfma(L, c->acc_dtype, max_d, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
                : launch_tap_generic(L, in_dtype, c->acc_dtype, max_d, s, &grid, &c->last_lds[0]);
         grid_total += grid;

@@ -1,0 +1,332 @@
+// fp16 tap for head_dim = 64 (every SDXL layer), gfx950, built on v_mfma_f32_16x16x32_f16.
+//
+// Why a second tiling: with 32x32 MFMA tiles a lane owns one pixel and 40 token slots, so the
+// softmax state (logits, exponentials, running sums) plus three 16-register accumulator tiles push
+// the kernel to 160+ VGPRs = 3 waves per SIMD, and the phase timers show the kernel is latency /
+// occupancy bound there (VALU ~50 % busy).  With 16x16 tiles the 77 tokens of a pixel are spread
+// over FOUR lanes (20 slots each), the live softmax state per 16-pixel group halves, and a wave
+// processes its 32 pixels as two groups whose MFMA and softmax phases interleave: 4 waves per SIMD.
+//
+// Same arithmetic / rounding points as daam_tap_mfma.hip:
+//   logits = fp16(f32(q.k) * scale) -> f32 softmax -> fp16(p) -> acc += p (accumulator dtype).
+//
+// Workgroup = 256 threads = 4 waves = 128 pixels of one (layer, kept head); wave w: pixels
+// [32w, 32w+32) = groups 0 / 1 of 16.  "Swapped" product S^T = K Q^T: A = K rows from LDS (lane:
+// token row l&15 of the 16-row tile, k = 8*(l>>4)..+7 of the 32-wide k-step), B = Q^T straight
+// from HBM (lane: pixel l&15, same k split) - each lane fetches 2 x 16 bytes per group and the four
+// lanes of a pixel cover one contiguous 64-byte half row per k-step.  C/D: lane holds pixel
+// l&15 and tokens 16*mt + 4*(l>>4) + r (mt = 0..4, r = 0..3) = 20 slots.
+// K of a step sits in LDS as [80 rows][128 B + 32 B pad] (pad 32: conflict-free ds_read_b128 for
+// this access pattern), double-buffered, register-staged one step ahead like the generic kernel.
+#include "daam_tap_common.h"
+
+namespace daam {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kD64Row = 160;                       // bytes per K row in LDS (128 + 32 pad)
+constexpr int kD64Rows = 80;                       // 5 MFMA row tiles; rows 77..79 stay zero
+constexpr int kD64KBuf = kD64Rows * kD64Row;       // 12800
+constexpr int kSlots16 = 20;                       // token slots per lane
+
+template <typename ACC_T> constexpr size_t tap_d64_lds_bytes() {
+    const size_t kb = 2 * (size_t)kD64KBuf, st = (size_t)kTok * kMfmaPixels * sizeof(ACC_T);
+    return (kb > st ? kb : st) + (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);
+}
+
+// token of slot i (= 4*mt + r) for lane quarter h
+__device__ __forceinline__ constexpr int slot16_token(int i, int h) { return 16 * (i >> 2) + 4 * h + (i & 3); }
+
+// all-reduce over the four lanes (l, l^16, l^32, l^48) that share a pixel, on the VALU
+// (v_permlane16_swap / v_permlane32_swap exchange, no LDS crossbar)
+__device__ __forceinline__ float quad_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// softmax over the 77 tokens of the lane's pixel (20 slots here, 57 in the three partner lanes)
+// + accumulate.  c[mt][r] = f32 q.k of token 16mt + 4h + r.
+template <typename ACC_T, bool FAST_EXP>
+__device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], const TapLayer& lay, int h,
+                                                     ACC_T (&run)[kSlots16])
+{
+    if constexpr (FAST_EXP) {
+        // see softmax_accumulate() in daam_tap_common.h for the error analysis of this path
+        half2v xh[kSlots16 / 2];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+            xh[2 * mt] = half2v{(_Float16)(c[mt][0] * lay.scale), (_Float16)(c[mt][1] * lay.scale)};
+            xh[2 * mt + 1] = half2v{(_Float16)(c[mt][2] * lay.scale), (_Float16)(c[mt][3] * lay.scale)};
+        }
+        if (h == 3) {                                                   // tokens 77, 78, 79
+            const _Float16 ninf = -(_Float16)__builtin_inff();
+            xh[8][1] = ninf;
+            xh[9] = half2v{ninf, ninf};
+        }
+        half2v ma = xh[0], mb = xh[1];
+#pragma unroll
+        for (int i = 2; i < kSlots16 / 2; i += 2) {
+            ma = __builtin_elementwise_max(ma, xh[i]);
+            mb = __builtin_elementwise_max(mb, xh[i + 1]);
+        }
+        ma = __builtin_elementwise_max(ma, mb);
+        const float m = quad_max(fmaxf((float)ma[0], (float)ma[1]));
+        const float L = 1.44269502162933349609375f;
+        const float nmL = -m * L;
+        float2v ev[kSlots16 / 2];
+        float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < kSlots16 / 2; i += 2) {
+            ev[i] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][0], L, nmL)),
+                            __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][1], L, nmL))};
+            ev[i + 1] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][0], L, nmL)),
+                                __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][1], L, nmL))};
+            sa += ev[i];
+            sb += ev[i + 1];
+        }
+        sa += sb;
+        const float inv = 1.0f / quad_sum(sa[0] + sa[1]);
+#pragma unroll
+        for (int i = 0; i < kSlots16 / 2; ++i) {
+            const float2v p = ev[i] * inv;
+            const half2v ph = {(_Float16)p[0], (_Float16)p[1]};          // probs.to(dtype)
+            if constexpr (sizeof(ACC_T) == 2) {                          // heatmap.py:156, as v_pk_add_f16
+                half2v r = {(_Float16)run[2 * i], (_Float16)run[2 * i + 1]};
+                r += ph;
+                run[2 * i] = (ACC_T)r[0];
+                run[2 * i + 1] = (ACC_T)r[1];
+            } else {
+                run[2 * i] = run[2 * i] + (ACC_T)ph[0];
+                run[2 * i + 1] = run[2 * i + 1] + (ACC_T)ph[1];
+            }
+        }
+    } else {
+        float x[kSlots16];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = c[mt][r] * lay.scale;                    // alpha in f32, then the baddbmm output rounding
+                x[4 * mt + r] = lay.round_logits ? (float)(_Float16)v : v;
+            }
+        if (h == 3) { x[17] = kMasked; x[18] = kMasked; x[19] = kMasked; }
+        float m0 = x[0], m1 = x[1], m2 = x[2], m3 = x[3];
+#pragma unroll
+        for (int i = 4; i < kSlots16; i += 4) {
+            m0 = fmaxf(m0, x[i]); m1 = fmaxf(m1, x[i + 1]); m2 = fmaxf(m2, x[i + 2]); m3 = fmaxf(m3, x[i + 3]);
+        }
+        const float m = quad_max(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kSlots16; i += 4) {
+            x[i] = exp_nonpos(x[i] - m);         s0 += x[i];
+            x[i + 1] = exp_nonpos(x[i + 1] - m); s1 += x[i + 1];
+            x[i + 2] = exp_nonpos(x[i + 2] - m); s2 += x[i + 2];
+            x[i + 3] = exp_nonpos(x[i + 3] - m); s3 += x[i + 3];
+        }
+        const float inv = 1.0f / quad_sum((s0 + s1) + (s2 + s3));
+#pragma unroll
+        for (int i = 0; i < kSlots16; ++i) {
+            const _Float16 prob = (_Float16)(x[i] * inv);                // probs.to(dtype)
+            run[i] = run[i] + (ACC_T)prob;                               // heatmap.py:156
+        }
+    }
+}
+
+template <typename ACC_T, bool FAST_EXP>
+__global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
+{
+    constexpr int KCH = (kTok * 8 + 255) / 256;               // 16-B K pieces per thread per step (3)
+    constexpr int VEC = AccVec<ACC_T>::kPerVec;
+    constexpr int PPR = kMfmaPixels / VEC;
+    constexpr size_t kPtrOff = tap_d64_lds_bytes<ACC_T>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* kbuf = smem;                               // [2][kD64KBuf]
+    ACC_T* stage = reinterpret_cast<ACC_T*>(smem);            // [kTok][kMfmaPixels], aliases kbuf
+    const void** sptr = reinterpret_cast<const void**>(smem + kPtrOff);
+
+    const int wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
+    if (wg < 0) return;
+    TapLayer lay;
+    const bool table = L.layers != nullptr;
+    if (table) {
+        const DAAM_GLOBAL TapLayer* gl = as_global<TapLayer>(L.layers);
+        load_layer(gl + mfma_find_layer(gl, L.n_layers, wg), &lay);
+    } else {
+        lay = L.one;
+    }
+    const int tid = threadIdx.x;
+    if (table) {
+        const DAAM_GLOBAL TapPtr* ptrs = as_global<TapPtr>(L.ptrs) + lay.ptr_begin;
+        for (int i = tid; i < lay.n_steps; i += 256) {
+            sptr[2 * i] = ptrs[i].q;
+            sptr[2 * i + 1] = ptrs[i].k;
+        }
+    } else if (tid == 0) {
+        sptr[0] = L.one_ptr.q;
+        sptr[1] = L.one_ptr.k;
+    }
+    const int n_steps = lay.n_steps;
+    const int rel = wg - lay.wg_begin;
+    const int kh = rel / lay.tiles_per_head;
+    const int p0 = (rel - kh * lay.tiles_per_head) * kMfmaPixels;
+    const int bh = lay.bh_first + kh;
+    const int b = bh / lay.heads, hd = bh - b * lay.heads;
+    const int64_t k_off = b * lay.k_sb + hd * lay.k_sh;
+    const int64_t q_off = b * lay.q_sb + hd * lay.q_sh;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, h = lane >> 4;
+
+    // ---- running sums -> registers (through the staging tile, 16-byte row pieces) --------------
+    ACC_T run0[kSlots16], run1[kSlots16];
+    ACC_T* acc = reinterpret_cast<ACC_T*>(lay.acc) + (size_t)kh * kTok * lay.hw;
+    if (!lay.fresh) {
+        for (int piece = tid; piece < kTok * PPR; piece += 256) {
+            const int row = piece / PPR, col = (piece - row * PPR) * VEC;
+            if (p0 + col < lay.hw)
+                *reinterpret_cast<float4v*>(stage + row * kMfmaPixels + col) =
+                    *as_global<float4v>(acc + (size_t)row * lay.hw + p0 + col);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kSlots16; ++i) {
+            const int t = slot16_token(i, h);
+            run0[i] = t < kTok ? stage[t * kMfmaPixels + wave * 32 + j] : (ACC_T)0;
+            run1[i] = t < kTok ? stage[t * kMfmaPixels + wave * 32 + 16 + j] : (ACC_T)0;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kSlots16; ++i) { run0[i] = (ACC_T)0; run1[i] = (ACC_T)0; }
+    }
+    __syncthreads();                                          // staging reads done; sptr visible
+    // K rows 77..79 (never written by a step) must be finite: zero them once, both buffers
+    for (int i = tid; i < 2 * 3 * (kD64Row / 16); i += 256) {
+        const int buf = i / (3 * (kD64Row / 16)), r = i % (3 * (kD64Row / 16));
+        *reinterpret_cast<float4v*>(kbuf + buf * kD64KBuf + kTok * kD64Row + r * 16) = float4v{0, 0, 0, 0};
+    }
+
+    // per-thread K piece coordinates: piece c = tid + 256 j2 -> row c / 8, piece c % 8
+    int k_src[KCH], k_dst[KCH];
+#pragma unroll
+    for (int j2 = 0; j2 < KCH; ++j2) {
+        const int c = tid + 256 * j2;
+        const int t = c >> 3, ch = c & 7;
+        k_src[j2] = min(t, kTok - 1) * (int)lay.k_st + ch * 8;
+        k_dst[j2] = t < kTok ? t * kD64Row + ch * 16 : -1;
+    }
+    const int px0 = min(p0 + wave * 32 + j, lay.hw - 1), px1 = min(p0 + wave * 32 + 16 + j, lay.hw - 1);
+    const int64_t q_row0 = q_off + (int64_t)px0 * lay.q_sp + h * 8;
+    const int64_t q_row1 = q_off + (int64_t)px1 * lay.q_sp + h * 8;
+
+    float4v kreg[KCH];
+    half8 bq0[2], bq1[2];
+    auto issue_k = [&](int s) {
+        const _Float16* kp = reinterpret_cast<const _Float16*>(sptr[2 * s + 1]) + k_off;
+#pragma unroll
+        for (int j2 = 0; j2 < KCH; ++j2) kreg[j2] = *as_global<float4v>(kp + k_src[j2]);
+    };
+    auto commit_k = [&](int buf) {
+#pragma unroll
+        for (int j2 = 0; j2 < KCH; ++j2)
+            if (k_dst[j2] >= 0) *reinterpret_cast<float4v*>(kbuf + buf * kD64KBuf + k_dst[j2]) = kreg[j2];
+    };
+    auto issue_q = [&](int s) {
+        const _Float16* qp = reinterpret_cast<const _Float16*>(sptr[2 * s]);
+        bq0[0] = *as_global<half8>(qp + q_row0);
+        bq0[1] = *as_global<half8>(qp + q_row0 + 32);
+        bq1[0] = *as_global<half8>(qp + q_row1);
+        bq1[1] = *as_global<half8>(qp + q_row1 + 32);
+    };
+    const unsigned char* a_rd = kbuf + j * kD64Row + h * 16;  // + buf * kD64KBuf + mt * 16 rows + ks * 64
+
+    issue_k(0);
+    issue_q(0);
+    commit_k(0);
+    for (int s = 0; s < n_steps; ++s) {
+        __syncthreads();
+        const unsigned char* kb = a_rd + (s & 1) * kD64KBuf;
+        floatx4 c0[5], c1[5];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+            const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kD64Row);
+            const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kD64Row + 64);
+            c0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bq0[0], floatx4{0, 0, 0, 0}, 0, 0, 0);
+            c1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bq1[0], floatx4{0, 0, 0, 0}, 0, 0, 0);
+            c0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bq0[1], c0[mt], 0, 0, 0);
+            c1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bq1[1], c1[mt], 0, 0, 0);
+        }
+        const int nx = min(s + 1, n_steps - 1);               // branch-free: the last step re-fetches itself
+        issue_k(nx);
+        issue_q(nx);
+        softmax20_accumulate<ACC_T, FAST_EXP>(c0, lay, h, run0);
+        softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
+        commit_k((s + 1) & 1);
+    }
+    __syncthreads();                                          // all K reads done before the staging tile reuses the space
+
+    // ---- write back: registers -> LDS [token][pixel] -> 16-byte row pieces -------------------
+#pragma unroll
+    for (int i = 0; i < kSlots16; ++i) {
+        const int t = slot16_token(i, h);
+        if (t < kTok) {
+            stage[t * kMfmaPixels + wave * 32 + j] = run0[i];
+            stage[t * kMfmaPixels + wave * 32 + 16 + j] = run1[i];
+        }
+    }
+    __syncthreads();
+    for (int piece = tid; piece < kTok * PPR; piece += 256) {
+        const int row = piece / PPR, col = (piece - row * PPR) * VEC;
+        if (p0 + col < lay.hw)
+            *as_global_rw<float4v>(acc + (size_t)row * lay.hw + p0 + col) =
+                *reinterpret_cast<const float4v*>(stage + row * kMfmaPixels + col);
+    }
+}
+
+bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+                       const void* q, const void* k)
+{
+    if (head_dim != 64) return false;
+    const int64_t s[] = {q_sp, k_st, q_sb, q_sh, k_sb, k_sh};
+    for (int64_t v : s)
+        if (v % 8 != 0) return false;
+    if (k_st * 77 >= (int64_t)1 << 30) return false;         // K element offsets are kept in 32 bits
+    return ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
+}
+
+template <typename ACC_T, bool FAST>
+static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out)
+{
+    const size_t lds = tap_d64_lds_bytes<ACC_T>();
+    *lds_out = lds;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_d64_kernel<ACC_T, FAST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((tap_d64_kernel<ACC_T, FAST>), dim3(grid), dim3(256), lds, stream, L);
+    return hipGetLastError();
+}
+
+hipError_t launch_tap_d64(const TapLaunch& L, int acc_dtype, int fast_exp, hipStream_t stream, int* grid_out, int* lds_out)
+{
+    const int grid = L.wgs_per_xcd * 8;
+    *grid_out = grid;
+    size_t lds = 0;
+    hipError_t e;
+    if (fast_exp) e = acc_dtype == 0 ? launch_d64<_Float16, true>(L, stream, grid, &lds) : launch_d64<float, true>(L, stream, grid, &lds);
+    else e = acc_dtype == 0 ? launch_d64<_Float16, false>(L, stream, grid, &lds) : launch_d64<float, false>(L, stream, grid, &lds);
+    *lds_out = (int)lds;
+    return e;
+}
+
+}  // namespace daam
