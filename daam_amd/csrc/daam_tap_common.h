@@ -56,6 +56,24 @@ __device__ __forceinline__ float exp_nonpos(float d) {
     return __builtin_fmaf(r, err * 0.693147182f, r);
 }
 
+// f32 pair -> packed fp16, round-to-nearest-even, as ONE v_cvt_pk_f16_f32.  Left to itself the
+// compiler folds the preceding multiply into v_fma_mixlo_f16 / v_fma_mixhi_f16, which measured
+// 3.4 ns per wave-instruction per SIMD against 1.8 ns for v_cvt_pk_f16_f32 (tools/ubench_valu.hip)
+// and handles one element instead of two.
+__device__ __forceinline__ half2v cvt_pk_rne(float2v v) {
+    half2v r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(v[0]), "v"(v[1]));
+    return r;
+}
+
+// packed fp16 max without the canonicalising v_pk_max_f16 x, x the compiler puts in front of
+// __builtin_elementwise_max when it cannot prove its inputs are not signalling NaNs
+__device__ __forceinline__ half2v pk_max(half2v a, half2v b) {
+    half2v r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // token of slot i for lane half g:  C/D row = (reg&3) + 8*(reg>>2) + 4*g  (+32 per row tile)
 __device__ __forceinline__ constexpr int slot_token(int i, int g) {
     const int mt = i >> 4, reg = i & 15;
@@ -86,12 +104,12 @@ __device__ __forceinline__ void softmax_accumulate(const floatx16& c0, const flo
             half2v xh[kSlots / 2];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                xh[i] = half2v{(_Float16)(c0[2 * i] * lay.scale), (_Float16)(c0[2 * i + 1] * lay.scale)};
-                xh[8 + i] = half2v{(_Float16)(c1[2 * i] * lay.scale), (_Float16)(c1[2 * i + 1] * lay.scale)};
+                xh[i] = cvt_pk_rne(float2v{c0[2 * i], c0[2 * i + 1]} * lay.scale);
+                xh[8 + i] = cvt_pk_rne(float2v{c1[2 * i], c1[2 * i + 1]} * lay.scale);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                xh[16 + i] = half2v{(_Float16)(c2[2 * i] * lay.scale), (_Float16)(c2[2 * i + 1] * lay.scale)};
+                xh[16 + i] = cvt_pk_rne(float2v{c2[2 * i], c2[2 * i + 1]} * lay.scale);
             if (g == 1) {                                                // tokens 77..79 of the upper lane half
                 const _Float16 ninf = -(_Float16)__builtin_inff();
                 xh[18][1] = ninf;
@@ -100,10 +118,10 @@ __device__ __forceinline__ void softmax_accumulate(const floatx16& c0, const flo
             half2v ma = xh[0], mb = xh[1];
 #pragma unroll
             for (int i = 2; i < kSlots / 2; i += 2) {
-                ma = __builtin_elementwise_max(ma, xh[i]);
-                mb = __builtin_elementwise_max(mb, xh[i + 1]);
+                ma = pk_max(ma, xh[i]);
+                mb = pk_max(mb, xh[i + 1]);
             }
-            ma = __builtin_elementwise_max(ma, mb);
+            ma = pk_max(ma, mb);
             float m = fmaxf((float)ma[0], (float)ma[1]);
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             const float L = 1.44269502162933349609375f;
@@ -125,8 +143,7 @@ __device__ __forceinline__ void softmax_accumulate(const floatx16& c0, const flo
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int i = 0; i < kSlots / 2; ++i) {
-                const float2v p = ev[i] * inv;
-                const half2v ph = {(_Float16)p[0], (_Float16)p[1]};      // probs.to(dtype)
+                const half2v ph = cvt_pk_rne(ev[i] * inv);                // probs.to(dtype)
                 if constexpr (sizeof(ACC_T) == 2) {                      // heatmap.py:156, as v_pk_add_f16
                     half2v r = {(_Float16)run[2 * i], (_Float16)run[2 * i + 1]};
                     r += ph;

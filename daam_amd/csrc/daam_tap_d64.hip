@@ -54,17 +54,22 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 // softmax over the 77 tokens of the lane's pixel (20 slots here, 57 in the three partner lanes)
 // + accumulate.  c[mt][r] = f32 q.k of token 16mt + 4h + r.
+template <typename ACC_T> struct Pair;
+template <> struct Pair<_Float16> { using T = half2v; };
+template <> struct Pair<float> { using T = float2v; };
+
 template <typename ACC_T, bool FAST_EXP>
 __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], const TapLayer& lay, int h,
-                                                     ACC_T (&run)[kSlots16])
+                                                     typename Pair<ACC_T>::T (&run)[kSlots16 / 2])
 {
+    using P2 = typename Pair<ACC_T>::T;
     if constexpr (FAST_EXP) {
         // see softmax_accumulate() in daam_tap_common.h for the error analysis of this path
         half2v xh[kSlots16 / 2];
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
-            xh[2 * mt] = half2v{(_Float16)(c[mt][0] * lay.scale), (_Float16)(c[mt][1] * lay.scale)};
-            xh[2 * mt + 1] = half2v{(_Float16)(c[mt][2] * lay.scale), (_Float16)(c[mt][3] * lay.scale)};
+            xh[2 * mt] = cvt_pk_rne(float2v{c[mt][0], c[mt][1]} * lay.scale);
+            xh[2 * mt + 1] = cvt_pk_rne(float2v{c[mt][2], c[mt][3]} * lay.scale);
         }
         if (h == 3) {                                                   // tokens 77, 78, 79
             const _Float16 ninf = -(_Float16)__builtin_inff();
@@ -74,10 +79,10 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
         half2v ma = xh[0], mb = xh[1];
 #pragma unroll
         for (int i = 2; i < kSlots16 / 2; i += 2) {
-            ma = __builtin_elementwise_max(ma, xh[i]);
-            mb = __builtin_elementwise_max(mb, xh[i + 1]);
+            ma = pk_max(ma, xh[i]);
+            mb = pk_max(mb, xh[i + 1]);
         }
-        ma = __builtin_elementwise_max(ma, mb);
+        ma = pk_max(ma, mb);
         const float m = quad_max(fmaxf((float)ma[0], (float)ma[1]));
         const float L = 1.44269502162933349609375f;
         const float nmL = -m * L;
@@ -96,17 +101,8 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
         const float inv = 1.0f / quad_sum(sa[0] + sa[1]);
 #pragma unroll
         for (int i = 0; i < kSlots16 / 2; ++i) {
-            const float2v p = ev[i] * inv;
-            const half2v ph = {(_Float16)p[0], (_Float16)p[1]};          // probs.to(dtype)
-            if constexpr (sizeof(ACC_T) == 2) {                          // heatmap.py:156, as v_pk_add_f16
-                half2v r = {(_Float16)run[2 * i], (_Float16)run[2 * i + 1]};
-                r += ph;
-                run[2 * i] = (ACC_T)r[0];
-                run[2 * i + 1] = (ACC_T)r[1];
-            } else {
-                run[2 * i] = run[2 * i] + (ACC_T)ph[0];
-                run[2 * i + 1] = run[2 * i + 1] + (ACC_T)ph[1];
-            }
+            const half2v ph = cvt_pk_rne(ev[i] * inv);                    // probs.to(dtype)
+            run[i] += P2{(ACC_T)ph[0], (ACC_T)ph[1]};                     // heatmap.py:156 (v_pk_add_f16 / v_pk_add_f32)
         }
     } else {
         float x[kSlots16];
@@ -136,7 +132,7 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
 #pragma unroll
         for (int i = 0; i < kSlots16; ++i) {
             const _Float16 prob = (_Float16)(x[i] * inv);                // probs.to(dtype)
-            run[i] = run[i] + (ACC_T)prob;                               // heatmap.py:156
+            run[i >> 1][i & 1] = run[i >> 1][i & 1] + (ACC_T)prob;       // heatmap.py:156
         }
     }
 }
@@ -188,7 +184,7 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_ker
     const int j = lane & 15, h = lane >> 4;
 
     // ---- running sums -> registers (through the staging tile, 16-byte row pieces) --------------
-    ACC_T run0[kSlots16], run1[kSlots16];
+    typename Pair<ACC_T>::T run0[kSlots16 / 2], run1[kSlots16 / 2];   // slot pairs (2i, 2i+1)
     ACC_T* acc = reinterpret_cast<ACC_T*>(lay.acc) + (size_t)kh * kTok * lay.hw;
     if (!lay.fresh) {
         for (int piece = tid; piece < kTok * PPR; piece += 256) {
@@ -201,12 +197,12 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_ker
 #pragma unroll
         for (int i = 0; i < kSlots16; ++i) {
             const int t = slot16_token(i, h);
-            run0[i] = t < kTok ? stage[t * kMfmaPixels + wave * 32 + j] : (ACC_T)0;
-            run1[i] = t < kTok ? stage[t * kMfmaPixels + wave * 32 + 16 + j] : (ACC_T)0;
+            run0[i >> 1][i & 1] = t < kTok ? stage[t * kMfmaPixels + wave * 32 + j] : (ACC_T)0;
+            run1[i >> 1][i & 1] = t < kTok ? stage[t * kMfmaPixels + wave * 32 + 16 + j] : (ACC_T)0;
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < kSlots16; ++i) { run0[i] = (ACC_T)0; run1[i] = (ACC_T)0; }
+        for (int i = 0; i < kSlots16; ++i) { run0[i >> 1][i & 1] = (ACC_T)0; run1[i >> 1][i & 1] = (ACC_T)0; }
     }
     __syncthreads();                                          // staging reads done; sptr visible
     // K rows 77..79 (never written by a step) must be finite: zero them once, both buffers
@@ -279,8 +275,8 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_ker
     for (int i = 0; i < kSlots16; ++i) {
         const int t = slot16_token(i, h);
         if (t < kTok) {
-            stage[t * kMfmaPixels + wave * 32 + j] = run0[i];
-            stage[t * kMfmaPixels + wave * 32 + 16 + j] = run1[i];
+            stage[t * kMfmaPixels + wave * 32 + j] = run0[i >> 1][i & 1];
+            stage[t * kMfmaPixels + wave * 32 + 16 + j] = run1[i >> 1][i & 1];
         }
     }
     __syncthreads();
