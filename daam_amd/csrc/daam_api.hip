@@ -22,12 +22,10 @@ bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t 
 int tap_mfma_tile_pixels();
 int tap_mfma_ksteps(int head_dim);
 int tap_mfma_max_steps();
-hipError_t launch_tap_mfma64(const TapLaunch&, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
 hipError_t launch_tap_d64(const TapLaunch&, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
 bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                        const void* q, const void* k);
-bool tap_mfma64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb,
-                          int64_t k_sh, const void* q, const void* k);
+
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
 hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
@@ -171,7 +169,6 @@ struct DaamCtx {
     int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
     int force_generic = 0;
     int fast_exp = 0;
-    int no_dma = 0;
     int no_d64 = 0;
 };
 
@@ -401,7 +398,7 @@ static bool use_mfma(const DaamCtx* c, const DaamQKDesc& d, const void* q, const
 }
 
 // kernel choice for an MFMA-capable call: 65 = 16x16-tile head_dim-64 kernel (default for d = 64),
-// 64 = LDS-DMA variant (opt-in), else the k-step count of the generic MFMA kernel
+// else the k-step count of the generic 32x32-tile MFMA kernel
 static int mfma_kind(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k);
 
 static bool use_d64(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
@@ -410,15 +407,8 @@ static bool use_d64(const DaamCtx* c, const DaamQKDesc& d, const void* q, const 
                                            d.k_stride_b, d.k_stride_h, q, k);
 }
 
-static bool use_mfma64(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
-{
-    return !c->no_dma && tap_mfma64_supported(d.head_dim, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h,
-                                              d.k_stride_b, d.k_stride_h, q, k);
-}
-
 static int mfma_kind(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
-    if (use_mfma64(c, d, q, k)) return 64;
     if (use_d64(c, d, q, k)) return 65;
     return tap_mfma_ksteps(d.head_dim);
 }
@@ -441,8 +431,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     L.wgs_per_xcd = (L.total_wgs + 7) / 8;
     c->last_block[0] = 256;
     const int kd1 = mfma ? mfma_kind(c, *d, q, k) : 0;
-    hipError_t e = kd1 == 64 ? launch_tap_mfma64(L, c->acc_dtype, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
-                   : kd1 == 65 ? launch_tap_d64(L, c->acc_dtype, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+    hipError_t e = kd1 == 65 ? launch_tap_d64(L, c->acc_dtype, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                         : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
                                              &c->last_grid[0], &c->last_lds[0]);
@@ -585,8 +574,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         L.total_wgs = wg;
         L.wgs_per_xcd = (wg + 7) / 8;
         int grid = 0;
-        e = kd == 64 ? launch_tap_mfma64(L, c->acc_dtype, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
-          : kd == 65 ? launch_tap_d64(L, c->acc_dtype, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
+        e = kd == 65 ? launch_tap_d64(L, c->acc_dtype, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
           : kd ? launch_tap_mfma(L, c->acc_dtype, max_d, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
                : launch_tap_generic(L, in_dtype, c->acc_dtype, max_d, s, &grid, &c->last_lds[0]);
         grid_total += grid;

@@ -257,11 +257,11 @@ def test_trace_api_matches_reference_golden(golden_case, tap, defer):
     assert out.images
 
 
-@pytest.mark.parametrize('env', [dict(DAAM_STRICT_EXP='1'), dict(DAAM_DMA='1'), dict(DAAM_DMA='1', DAAM_STRICT_EXP='1'),
+@pytest.mark.parametrize('env', [dict(DAAM_STRICT_EXP='1'), dict(DAAM_NO_D64='1'), dict(DAAM_NO_D64='1', DAAM_STRICT_EXP='1'),
                                  dict(DAAM_FORCE_GENERIC='1')])
 def test_optional_kernel_paths_keep_parity(env, monkeypatch):
-    """The opt-in / fallback kernel variants (compensated-exp softmax, LDS-DMA operands for head_dim 64, the
-    any-shape kernels) stay within the same tolerances on an SDXL-shaped fp16 case (head_dim 64)."""
+    """The opt-in / fallback kernel variants (compensated-exp softmax, the 32x32-tile MFMA kernel instead of the
+    head_dim-64 one, the any-shape kernels) stay within the same tolerances on an SDXL-shaped fp16 case (head_dim 64)."""
     import daam_amd
     for k, v in env.items():
         monkeypatch.setenv(k, v)
