@@ -241,12 +241,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->force_generic = fg && fg[0] == '1';
     const char* nm = getenv("DAAM_NO_MFMA_FINALIZE");
     c->no_mfma_finalize = nm && nm[0] == '1';
-    // the LDS-DMA operand kernel (head_dim 64) is correct but measured 10 % slower than the register
-    // path on MI355X (round 1): opt-in for experiments
-    const char* n16 = getenv("DAAM_NO_D64");
+    const char* n16 = getenv("DAAM_NO_D64");            // debugging: 32x32-tile kernel also for head_dim 64
     c->no_d64 = n16 && n16[0] == '1';
-    const char* nd = getenv("DAAM_DMA");
-    c->no_dma = !(nd && nd[0] == '1');
     // softmax flavour of the MFMA tap: fast (default; exponent by one mixed-precision FMA, ~1e-6 relative,
     // same deviation class as the f32 summation order of q.k -- DESIGN.md section 3.1) or compensated
     // (DAAM_STRICT_EXP=1 / DAAM_FAST_EXP=0: ~1 ulp f32 like the reference's expf)
