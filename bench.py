@@ -98,22 +98,24 @@ def tap_bytes(layers, steps_per_launch, acc_bytes, fresh):
 
 
 def measure_tap_kernel(eng, calls, defer, reps):
-    """HIP-event time of back-to-back tap launches (all Q/K pointers recorded first, so the
-    stream sees table upload + kernel only)."""
+    """HIP-event time of the tap kernel: libdaam_hip brackets its kernel launch(es) with events on
+    the launch stream (daam_profile_enable), the table upload in front of them is outside."""
+    import ctypes
+    from daam_amd import _native as nat
     stream = torch.cuda.current_stream()
     eng.clear()
+    nat.check(eng.lib.daam_profile_enable(eng.ctx, 1))
     times = []
     for r in range(reps + 2):
         for s in range(defer):
             for a in calls[(r * defer + s) % len(calls)]:
                 eng.tap_qk(*a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
         eng.flush()
-        e1.record(stream)
-        e1.synchronize()
+        ms = ctypes.c_float()
+        nat.check(eng.lib.daam_profile_last_ms(eng.ctx, 0, ctypes.byref(ms)))
         if r >= 2:                               # first launch after clear() skips the read; warm-up
-            times.append(e0.elapsed_time(e1))
+            times.append(ms.value)
+    nat.check(eng.lib.daam_profile_enable(eng.ctx, 0))
     return sum(times) / len(times)
 
 
@@ -282,7 +284,7 @@ def main():
                 traffic = rec.get('tap_bytes_per_launch') if rec else None
             except Exception:
                 traffic = None
-        roofline = dict(bound='hbm', kernel='tap_mfma_kernel<KS=4,fp16 sums>' if wl['kind'] == 'sdxl' else 'tap_mfma_kernel<KS=3|5|10>',
+        roofline = dict(bound='hbm', kernel='tap_d64_kernel (16x16x32 MFMA tiles, head_dim 64)' if wl['kind'] == 'sdxl' else 'tap_mfma_kernel<KS=3|5|10>',
                         achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
                         traffic=traffic, bytes_per_launch=int(bytes_launch), ms_per_launch=round(tap_ms, 4),
                         steps_per_launch=spl, launches_per_generation=launches_per_gen,

@@ -167,6 +167,8 @@ struct DaamCtx {
     std::vector<int> pending_last;    // per layer: index of its newest entry in `pending`
     void drop_pending() { pending.clear(); pending_count.clear(); pending_last.clear(); }
     int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
+    int profile = 0;
+    hipEvent_t prof_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int force_generic = 0;
     int fast_exp = 0;
     int no_d64 = 0;
@@ -260,6 +262,9 @@ int daam_ctx_destroy(DaamCtx* c)
     c->ring.destroy();
     for (auto& l : c->layers)
         if (l.owned && l.acc) (void)hipFree(l.acc);
+    for (auto& pair : c->prof_ev)
+        for (auto& ev : pair)
+            if (ev) (void)hipEventDestroy(ev);
     if (c->d_tab_idx) (void)hipFree(c->d_tab_idx);
     if (c->d_tab_w) (void)hipFree(c->d_tab_w);
     delete c;
@@ -528,6 +533,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         if (std::find(kinds.begin(), kinds.end(), kd) == kinds.end()) kinds.push_back(kd);
     int rc = 0;
     int grid_total = 0;
+    bool ev_started = false;
     for (int kd : kinds) {
         size_t n_layers = 0, n_ptrs = 0;
         for (size_t i = 0; i < order.size(); ++i)
@@ -561,6 +567,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         }
         e = c->ring.commit(off, bytes, s);
         if (e != hipSuccess) { rc = fail((int)e, "table upload: %s", hipGetErrorString(e)); break; }
+        if (c->profile && !ev_started) { (void)hipEventRecord(c->prof_ev[0][0], s); ev_started = true; }
         TapLaunch L;
         memset(&L, 0, sizeof L);
         L.layers = reinterpret_cast<const TapLayer*>(c->ring.dev + off);
@@ -580,6 +587,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         for (size_t i = 0; i < order.size(); ++i)
             if (kind[i] == kd) { c->layers[order[i]].dirty = true; c->layers[order[i]].zero_pending = false; }
     }
+    if (c->profile && ev_started) (void)hipEventRecord(c->prof_ev[0][1], s);
     c->last_grid[0] = grid_total;
     c->last_block[0] = 256;
     c->drop_pending();
@@ -683,6 +691,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     c->last_grid[1] = 0;
     c->last_lds[1] = 0;
     static const int env_chunks = getenv("DAAM_FIN_CHUNKS") ? atoi(getenv("DAAM_FIN_CHUNKS")) : 0;
+    if (c->profile) (void)hipEventRecord(c->prof_ev[1][0], s);
     for (int cls = 0; cls < 4; ++cls) {
         const int n = (int)keys[cls].size();
         if (n == 0) { continue; }
@@ -717,6 +726,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         c->last_grid[1] += grid;
         c->last_lds[1] = std::max(c->last_lds[1], lds);
     }
+    if (c->profile) (void)hipEventRecord(c->prof_ev[1][1], s);
     HIP_TRY(c->ring.release(s));
     return 0;
 }
@@ -738,6 +748,25 @@ int daam_word_heat_map(const float* maps, int side, const int32_t* idx, int n_id
     hipError_t e = launch_word(maps, side, idx, n_idx, word_map, out, out_h, out_w, absolute, threshold, workspace,
                                (hipStream_t)stream);
     if (e != hipSuccess) return fail((int)e, "word map launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int daam_profile_enable(DaamCtx* c, int on)
+{
+    if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
+    if (on && !c->prof_ev[0][0])
+        for (auto& pair : c->prof_ev)
+            for (auto& ev : pair) HIP_TRY(hipEventCreate(&ev));
+    c->profile = on ? 1 : 0;
+    return 0;
+}
+
+int daam_profile_last_ms(DaamCtx* c, int which, float* ms)
+{
+    if (!c || !ms || which < 0 || which > 1) return fail(DAAM_E_INVALID, "bad argument");
+    if (!c->prof_ev[which][0]) return fail(DAAM_E_STATE, "profiling was never enabled");
+    HIP_TRY(hipEventSynchronize(c->prof_ev[which][1]));
+    HIP_TRY(hipEventElapsedTime(ms, c->prof_ev[which][0], c->prof_ev[which][1]));
     return 0;
 }
 

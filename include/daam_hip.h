@@ -142,6 +142,11 @@ const char* daam_last_error(void);
 /* per-kernel launch statistics of the last tap / finalize launch (for bench.py):
  * grid size and dynamic LDS bytes; 0 if nothing launched yet. */
 int daam_last_launch(DaamCtx* ctx, int which /*0 tap,1 finalize*/, int* grid, int* block, int* lds_bytes);
+/* kernel timing for bench.py: when enabled, every tap / finalize call brackets ITS KERNEL LAUNCHES (not
+ * the table upload before them) with HIP events on the call's stream; daam_profile_last_ms waits for the
+ * last pair and returns the elapsed milliseconds (the only other call that synchronises the host). */
+int daam_profile_enable(DaamCtx* ctx, int on);
+int daam_profile_last_ms(DaamCtx* ctx, int which /*0 tap,1 finalize*/, float* ms);
 
 #ifdef __cplusplus
 }

@@ -358,3 +358,76 @@ def test_full_size_layer_properties(heads, side, d):
     exact = os.environ.get('DAAM_STRICT_EXP', '0') == '1'      # the default (fast) softmax may be one fp16 ulp off here
     assert (acc - float(np.float16(1.0 / 77))).abs().max().item() <= (0.0 if exact else 2.0 ** -17)
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# property tests (hypothesis): random layer shapes / step counts / launch structures
+# ---------------------------------------------------------------------------------------------
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(heads=st.integers(1, 4), side=st.sampled_from([4, 8, 12, 16, 24]), d=st.sampled_from([8, 16, 24, 40, 64, 80]),
+       batch=st.sampled_from([1, 2, 4]), steps=st.integers(1, 5), defer=st.sampled_from([0, 1, 2, 7]),
+       mode=st.sampled_from(['f16_exact', 'f16_f32acc', 'f32']), seed=st.integers(0, 2 ** 16))
+def test_tap_property(heads, side, d, batch, steps, defer, mode, seed):
+    """Any (heads, map size, head_dim, CFG batch, steps, deferral) combination matches the oracle
+    within the stated tolerance and keeps the token sums at `steps`."""
+    hw = side * side
+    rng = np.random.default_rng(seed)
+    np_dt = np.float32 if mode == 'f32' else np.float16
+    acc_np = np.float16 if mode == 'f16_exact' else np.float32
+    scale = d ** -0.5
+    qs, ks = zip(*[_qk(rng, batch, heads, hw, d, np_dt) for _ in range(steps)])
+    want = _oracle_steps(qs, ks, heads, scale, np_dt, acc_np).astype(np.float64)
+    eng = _engine(accumulate='exact' if mode != 'f16_f32acc' else 'float32', defer_steps=defer)
+    for q, k in zip(qs, ks):
+        eng.tap_qk(0, torch.from_numpy(q).to(DEV), torch.from_numpy(k).to(DEV), heads, scale, factor=1)
+    got = np.stack([v.float().cpu().numpy() for _, v in eng.items()]).astype(np.float64)
+    eng.close()
+    assert got.shape == want.shape
+    tol = {'f32': 2e-6 * max(1.0, np.abs(want).max()), 'f16_exact': 2.0 ** -10 * max(1.0, want.max()),
+           'f16_f32acc': steps * 2.0 ** -11}[mode]
+    assert np.abs(got - want).max() <= tol
+    np.testing.assert_allclose(got.sum(1), steps, atol=steps * 77 * 2.0 ** -11)
+
+
+@settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(sides=st.lists(st.sampled_from([8, 16, 32, 64, 128]), min_size=1, max_size=4), acc=st.sampled_from(['float16', 'float32']),
+       heads=st.integers(1, 3), seed=st.integers(0, 2 ** 16))
+def test_finalize_property(sides, acc, heads, seed):
+    """Any mix of map sizes: mean over keys of clamp(bicubic(plane)) matches the oracle; linear in a
+    positive scale of the inputs (clamp and bicubic are positively homogeneous)."""
+    rng = np.random.default_rng(seed)
+    eng = _engine(n_layers=len(sides), accumulate='exact' if acc == 'float16' else 'float32')
+    eng2 = _engine(n_layers=len(sides), accumulate='exact' if acc == 'float16' else 'float32')
+    raw = []
+    for layer, side in enumerate(sides):
+        planes = (rng.standard_normal((2 * heads, side * side, 77)) * 2).astype(acc)
+        factor = 64 // side if side <= 64 else 0
+        eng.tap_probs(layer, torch.from_numpy(planes).to(DEV), factor=factor)
+        eng2.tap_probs(layer, torch.from_numpy((planes * np.asarray(2, dtype=acc))).to(DEV), factor=factor)
+        raw += [((factor, layer, h), ho.unravel(planes)[h]) for h in range(heads)]
+    want = ho.global_heat_map(raw, 4096)
+    got = eng.global_heat_map().cpu().numpy()
+    got2 = eng2.global_heat_map().cpu().numpy()
+    eng.close()
+    eng2.close()
+    tol = 3e-6 * max(1.0, np.abs(want).max())
+    np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+    np.testing.assert_allclose(got2, 2 * got, rtol=0, atol=4 * tol)
+
+
+def test_trace_prompts_single_process():
+    """daam_amd.distributed.trace_prompts without a process group = plain loop over the prompts."""
+    from daam_amd.distributed import trace_prompts
+    z, meta = load_golden('sd15_f16')
+    pipe = golden_pipe(meta, device=DEV)
+    prompts = ['a dog', 'a photo of a monkey']
+    maps, rows = trace_prompts(pipe, prompts, num_inference_steps=3)
+    assert maps.shape == (2, 77, 64, 64) and rows == [4, 7]
+    import daam_amd
+    with daam_amd.trace(pipe) as tc:
+        pipe(prompts[1], num_inference_steps=3)
+        ref = tc.compute_global_heat_map().heat_maps
+    assert torch.allclose(maps[1, :rows[1]], ref, rtol=0, atol=1e-6)

@@ -26,7 +26,7 @@ def find(d, suffix):
 def short(name):
     if 'daam' not in name:
         return None
-    for k in ('tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'finalize_up32_mfma_kernel',
+    for k in ('tap_d64_kernel', 'tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'finalize_up32_mfma_kernel',
               'finalize_up_kernel', 'finalize_same_kernel', 'finalize_kernel', 'normalize_kernel', 'word_'):
         if k in name:
             return k
@@ -71,9 +71,11 @@ def main():
         tpath = os.path.join(a.out, 'hbm_traffic.json')
         traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
         rec = {}
-        for kern, field in (('tap_mfma_kernel', 'tap'), ('finalize_up32_mfma_kernel', 'finalize_up'),
-                            ('finalize_same_kernel', 'finalize_same')):
+        for kern, field in (('tap_d64_kernel', 'tap'), ('tap_mfma_kernel', 'tap'),
+                            ('finalize_up32_mfma_kernel', 'finalize_up'), ('finalize_same_kernel', 'finalize_same')):
             cs = pmc.get(kern, {})
+            if f'{field}_bytes_per_launch' in rec:
+                continue
             if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
                 # the steady-state launch = the most common large one: take the upper median
                 fe = statistics.median(sorted(cs['FETCH_SIZE'])[len(cs['FETCH_SIZE']) // 2:])
