@@ -28,6 +28,7 @@ bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, i
 
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
+hipError_t launch_upload(void* dst, const void* src_host_mapped, size_t bytes, hipStream_t);
 hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
 hipError_t launch_finalize_up(const FinLaunch&, int side, int, int mfma_ok, hipStream_t, int*);
 bool finalize_up_supported(int side, int out_side);
@@ -62,12 +63,15 @@ namespace {
 
 // ---- pinned upload ring -----------------------------------------------------------------
 // alloc() hands out a pinned host region and its device twin; commit() copies it H2D on the
-// stream and, after the consuming kernel has been enqueued, release() records an event so the
-// region is only reused once that kernel has run.  Wrap-around waits (hipEventSynchronize)
+// stream with a tiny copy KERNEL that reads the (device-mapped) pinned buffer - hipMemcpyAsync put a
+// ~0.2 ms cross-queue bubble between the copy and the consuming kernel - and, after the consuming
+// kernel has been enqueued, release() records an event so the region is only reused once that
+// kernel has run.  Wrap-around waits (hipEventSynchronize)
 // only if the GPU is more than one ring behind the host.
 struct Ring {
     static constexpr size_t kBytes = 8u << 20;
     char* host = nullptr;
+    char* host_dev = nullptr;         // device-side address of the pinned buffer
     char* dev = nullptr;
     size_t head = 0;                  // next free byte
     struct Busy { size_t begin, end; hipEvent_t ev; };
@@ -75,7 +79,9 @@ struct Ring {
     std::vector<hipEvent_t> pool;
 
     hipError_t init() {
-        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&host), kBytes, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&host), kBytes, hipHostMallocMapped);
+        if (e != hipSuccess) return e;
+        e = hipHostGetDevicePointer(reinterpret_cast<void**>(&host_dev), host, 0);
         if (e != hipSuccess) return e;
         return hipMalloc(reinterpret_cast<void**>(&dev), kBytes);
     }
@@ -114,7 +120,7 @@ struct Ring {
     }
     size_t cur_begin = 0, cur_end = 0;
     hipError_t commit(size_t off, size_t bytes, hipStream_t s) {
-        return hipMemcpyAsync(dev + off, host + off, bytes, hipMemcpyHostToDevice, s);
+        return launch_upload(dev + off, host_dev + off, bytes, s);
     }
     hipError_t release(hipStream_t s) {
         hipEvent_t ev;

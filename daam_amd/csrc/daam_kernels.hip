@@ -355,6 +355,22 @@ __global__ __launch_bounds__(256) void word_post_kernel(float* out, int n, const
     out[i] = v;
 }
 
+// per-launch device tables: pinned host (device-mapped) -> device twin, in stream order on the
+// compute queue (16 bytes per thread; tables are a few tens of KB)
+__global__ __launch_bounds__(256) void upload_kernel(float4* dst, const float4* src, int n16)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
+hipError_t launch_upload(void* dst, const void* src_host_mapped, size_t bytes, hipStream_t stream)
+{
+    const int n16 = (int)((bytes + 15) / 16);                 // ring slots are 256-byte aligned and padded
+    hipLaunchKernelGGL(upload_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream, reinterpret_cast<float4*>(dst),
+                       reinterpret_cast<const float4*>(src_host_mapped), n16);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
 // host-callable launchers (called from daam_api.hip)
 // ---------------------------------------------------------------------------------------
