@@ -43,6 +43,9 @@ class HeatMapEngine:
         self.touched: List[int] = []                     # layers updated since clear(), first-update order
         # deferred taps: recorded per call (the tensors are kept alive until the flush)
         self._rec: List[tuple] = []                      # (layer, query, key, address of its DaamQKDesc)
+        # steps per launch: the first launch after clear() is kept short (the GPU has nothing else to
+        # do while the host records the first window), later ones use the full defer_steps
+        self._window = self._first_window()
         self._cnt: List[int] = [0] * self.n_layers      # recorded steps per layer
         self._qk_cache: List[Optional[tuple]] = [None] * self.n_layers
         self._touched_flag: List[bool] = [False] * self.n_layers
@@ -114,6 +117,7 @@ class HeatMapEngine:
         self._drop_recorded()
         self.touched.clear()
         self._touched_flag = [False] * self.n_layers
+        self._window = self._first_window()
         if self.ctx is not None:
             nat.check(self.lib.daam_reset(self.ctx, self.stream))
 
@@ -139,7 +143,7 @@ class HeatMapEngine:
         if self.defer_steps:
             # record only: pointers cross the FFI in one daam_tap_qk_enqueue_many call per flush
             n = cnt[layer]
-            if n >= self.defer_steps:
+            if n >= self._window:
                 self.flush()
                 n = 0
             cnt[layer] = n + 1
@@ -184,6 +188,9 @@ class HeatMapEngine:
         self._qk_cache[layer] = entry
         return query, key, entry
 
+    def _first_window(self) -> int:
+        return max(1, min(self.defer_steps, 4)) if self.defer_steps else 0
+
     def flush(self) -> None:
         """Run every recorded (deferred) tap; the held Q/K references are dropped afterwards
         (stream order keeps their memory valid until the kernel has consumed it)."""
@@ -191,14 +198,16 @@ class HeatMapEngine:
         n = len(rec)
         if self.ctx is None or n == 0:
             return
-        layers = np.fromiter((r[0] for r in rec), dtype=np.int32, count=n)
-        qp = np.fromiter((r[1].data_ptr() for r in rec), dtype=np.uint64, count=n)
-        kp = np.fromiter((r[2].data_ptr() for r in rec), dtype=np.uint64, count=n)
-        dp = np.fromiter((r[3] for r in rec), dtype=np.uint64, count=n)
+        lay_t, q_t, k_t, d_t = zip(*rec)                       # one C-level pass
+        layers = np.array(lay_t, dtype=np.int32)
+        qp = np.array([t.data_ptr() for t in q_t], dtype=np.uint64)
+        kp = np.array([t.data_ptr() for t in k_t], dtype=np.uint64)
+        dp = np.array(d_t, dtype=np.uint64)
         try:
             nat.check(self.lib.daam_tap_qk_enqueue_many(self.ctx, n, layers.ctypes.data, qp.ctypes.data, kp.ctypes.data,
                                                         dp.ctypes.data))
             nat.check(self.lib.daam_tap_flush(self.ctx, self.stream))
+            self._window = self.defer_steps
         finally:
             self._drop_recorded()
 

@@ -200,7 +200,8 @@ def test_engine_deferred_bookkeeping(fake_engine):
     for step in range(5):
         for layer in (2, 0, 1):                       # execution order != locator order
             eng.tap_qk(layer, q[layer], k[layer], heads=2, scale=0.35, factor=8 // 8 or 1)
-    # 5 steps at 2 per launch: flushed after steps 2 and 4 (when step 3 / 5 arrive), 3 taps still recorded
+    # 5 steps at 2 per launch (the first window after clear() is min(defer, 4) = 2 as well): flushed after
+    # steps 2 and 4 (when step 3 / 5 arrive), 3 taps still recorded
     assert lib.names().count('daam_tap_flush') == 2
     many = [c for c in lib.calls if c[0] == 'daam_tap_qk_enqueue_many']
     assert [c[1][1] for c in many] == [6, 6]
