@@ -191,8 +191,8 @@ def eager_gpu_reference(kind, latent, denoise_steps, device, sample_steps=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20, help='timed generations per rank')
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50, help='timed generations per rank')
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='sdxl1024', choices=sorted(WORKLOADS))
     ap.add_argument('--denoise-steps', type=int, default=50)
     ap.add_argument('--defer', type=int, default=int(os.environ.get('DAAM_DEFER_STEPS', '16')),
