@@ -431,3 +431,24 @@ def test_trace_prompts_single_process():
         pipe(prompts[1], num_inference_steps=3)
         ref = tc.compute_global_heat_map().heat_maps
     assert torch.allclose(maps[1, :rows[1]], ref, rtol=0, atol=1e-6)
+
+
+def test_to_experiment_and_plot(tmp_path):
+    """trace.to_experiment (reference trace.py:68-81) -> save / load in the reference's layout, and the
+    overlay plot of a word map on a real image."""
+    import PIL.Image
+    import daam_amd
+    z, meta = load_golden('sd15_f16')
+    pipe = golden_pipe(meta, device=DEV)
+    with daam_amd.trace(pipe) as tc:
+        pipe('a dog', num_inference_steps=2)
+        tc.last_image = PIL.Image.fromarray(np.full((64, 64, 3), 128, dtype=np.uint8))
+        exp = tc.to_experiment(str(tmp_path), seed=3, id='g0', subtype='run')
+        ghm = tc.compute_global_heat_map()
+    assert exp.global_heat_map.shape == (4, 64, 64) and exp.prompt == 'a dog'
+    exp.save()
+    root = tmp_path / 'g0'
+    assert (root / 'run' / 'generation.pt').exists() and (root / 'run' / 'output.png').exists()
+    assert (root / 'run' / 'dog.heat_map.png').exists()                   # save_all_heat_maps
+    back = daam_amd.GenerationExperiment.load(root, subtype='run')
+    assert torch.equal(back.global_heat_map, ghm.heat_maps.cpu())

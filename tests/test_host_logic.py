@@ -269,3 +269,28 @@ def test_torch_port_matches_reference_golden(name):
         np.testing.assert_allclose(got, z[f'global_{vn}'], rtol=0, atol=tol * max(1.0, float(np.abs(z[f'global_{vn}']).max())))
     assert len(th.topology('sdxl')) == 60 and sum(h for _, h, _, _ in th.topology('sdxl')) == 1100
     assert len(th.topology('sd15')) == 15 and sum(h for _, h, _, _ in th.topology('sd15')) == 120
+
+
+# ------------------------------------------------------------------------------------------------
+# GenerationExperiment: the reference's on-disk layout (experiment.py:140-167, 303-344)
+# ------------------------------------------------------------------------------------------------
+def test_generation_experiment_round_trip(tmp_path):
+    from daam_amd import GenerationExperiment
+    import PIL.Image
+    img = PIL.Image.fromarray(np.full((8, 8, 3), 200, dtype=np.uint8))
+    maps = torch.rand(4, 64, 64)
+    exp = GenerationExperiment(img, maps, 'a dog', seed=7, id='p0', path=str(tmp_path), subtype='base',
+                               tokenizer=fd.FakeTokenizer())
+    assert exp.path == tmp_path / 'p0' and not exp.nsfw()
+    exp.annotate('k', [1, 2]).save()
+    root = tmp_path / 'p0'
+    assert (root / 'prompt.txt').read_text() == 'a dog' and (root / 'seed.txt').read_text() == '7'
+    assert (root / 'base' / 'generation.pt').exists() and (root / 'base' / 'output.png').exists()
+    assert json.loads((root / 'annotations.json').read_text()) == {'k': [1, 2]}
+    back = GenerationExperiment.load(root, subtype='base')
+    assert back.prompt == 'a dog' and back.seed == 7 and torch.equal(back.global_heat_map, maps)
+    assert back.annotations == {'k': [1, 2]} and back.subtype == 'base' and back.path == root
+    assert GenerationExperiment.read_seed(tmp_path, 'p0') == 7 and GenerationExperiment.read_prompt(root) == 'a dog'
+    assert back.heat_map().prompt == 'a dog'
+    back.clear_checkpoint()
+    assert not (root / 'base' / 'generation.pt').exists()
