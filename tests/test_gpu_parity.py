@@ -452,4 +452,5 @@ def test_to_experiment_and_plot(tmp_path):
     assert (root / 'run' / 'generation.pt').exists() and (root / 'run' / 'output.png').exists()
     assert (root / 'run' / 'dog.heat_map.png').exists()                   # save_all_heat_maps
     back = daam_amd.GenerationExperiment.load(root, subtype='run')
-    assert torch.equal(back.global_heat_map, ghm.heat_maps.cpu())
+    # two finalize calls: the f32 atomics may add the keys in a different order
+    assert torch.allclose(back.global_heat_map, ghm.heat_maps.cpu(), rtol=0, atol=1e-6)
