@@ -168,7 +168,6 @@ struct DaamCtx {
     std::vector<int> tab_sides;
     std::vector<int> tab_fp16_exact;   // every (border-merged) tap weight is an fp16 number
     int no_mfma_finalize = 0;
-    int mfma_finalize_kind = 2;        // 1: MFMA x pass + VALU y pass, 2: both passes on the matrix cores
     std::vector<Pending> pending;
     std::vector<int> pending_count;   // per layer: recorded steps
     std::vector<int> pending_last;    // per layer: index of its newest entry in `pending`
@@ -250,8 +249,6 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->force_generic = fg && fg[0] == '1';
     const char* nm = getenv("DAAM_NO_MFMA_FINALIZE");
     c->no_mfma_finalize = nm && nm[0] == '1';
-    const char* fk = getenv("DAAM_FINALIZE_MFMA");
-    if (fk && (fk[0] == '1' || fk[0] == '2')) c->mfma_finalize_kind = fk[0] - '0';
     const char* n16 = getenv("DAAM_NO_D64");            // debugging: 32x32-tile kernel also for head_dim 64
     c->no_d64 = n16 && n16[0] == '1';
     // softmax flavour of the MFMA tap: fast (default; exponent by one mixed-precision FMA, ~1e-6 relative,
@@ -729,7 +726,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             // more pays the per-workgroup reduction + atomics too often.
             const int want = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
             L.n_chunks = std::max(std::max(1, std::min((n + 3) / 4, want)), (n + 255) / 256);
-            e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, (c->tab_fp16_exact[keys[cls][0].tab] && !c->no_mfma_finalize) ? c->mfma_finalize_kind : 0, s, &grid);
+            e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, c->tab_fp16_exact[keys[cls][0].tab] && !c->no_mfma_finalize, s, &grid);
         }
         if (e != hipSuccess) return fail((int)e, "finalize launch (class %d): %s", cls, hipGetErrorString(e));
         c->last_grid[1] += grid;

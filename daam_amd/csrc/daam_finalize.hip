@@ -404,124 +404,6 @@ __global__ __launch_bounds__(256) void finalize_up32_mfma_kernel(const FinLaunch
                     L.out + (size_t)tok * O * O, L.inv_n);
 }
 
-// ---------------------------------------------------------------------------------------
-// x2 (32 -> 64) for fp16 planes with BOTH passes on the matrix cores.
-//   x pass as in finalize_up32_mfma_kernel:  T = A Wx^T   (T[y][ox], f32, C/D layout).
-//   y pass:  out = Wy T  with T as the B operand.  4 v_permlane32_swap per 8 registers turn the C/D
-//   layout (lane (j, g): rows 8b + 4g + r) into the B layout (lane (j, g): rows 16ks + 8g + e), and T
-//   is carried as an fp16 pair T = hi + lo (hi = fp16(T), lo = fp16(T - hi): 22 significant bits,
-//   |error| <= 2^-22 |T|, far inside the 3e-6 tolerance of the bicubic parity tests); the banded
-//   64x32 tap matrix Wy is exact in fp16 (host check).  The clamp + accumulate then runs on the C/D
-//   registers of the second product: lane (j, g) owns out[32mt + 8b + 4g + r][32nt + j].
-//   VALU work per plane drops from ~360 to ~200 instructions; the MFMA pipe does 20 instructions.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void finalize_up32_mfma2_kernel(const FinLaunch L)
-{
-    constexpr int S = 32, O = 64;
-    constexpr int kDepth = 2, kMaxKeysPerWave = 64;
-    __shared__ const void* kbase[4][kMaxKeysPerWave];
-    __shared__ __align__(16) float red[2 * O * O];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 31, g = lane >> 5;
-    const int tok = blockIdx.x;
-
-    const int tab = as_global<FinKey>(L.keys)[0].tab;
-    const int16_t* tix = L.tab_idx + (size_t)tab * O * 4;
-    const float* tw = L.tab_w + (size_t)tab * O * 4;
-
-    // banded tap matrix rows for output coordinate o = 32t + n, as fp16 pieces over source index
-    // 16ks + 8g + e: used as B of the x pass (Wx^T) and as A of the y pass (Wy)
-    half8 wm[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int o = 32 * t + n;
-        int ix[4];
-        float wv[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { ix[a] = tix[o * 4 + a]; wv[a] = tw[o * 4 + a]; }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int x = 16 * ks + 8 * g + e;
-                float w = 0.f;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) w += (ix[a] == x) ? wv[a] : 0.f;
-                wm[t][ks][e] = (_Float16)w;
-            }
-    }
-
-    // acc[mt][nt][v] = out[32mt + 8(v>>2) + 4g + (v&3)][32nt + n]
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = floatx16{0};
-
-    const int stride = gridDim.y * 4;
-    const int first = blockIdx.y * 4 + wave;
-    const int nk = first < L.n_keys ? min((L.n_keys - first + stride - 1) / stride, kMaxKeysPerWave) : 0;
-    if (lane < nk) kbase[wave][lane] = as_global<FinKey>(L.keys)[first + lane * stride].base;
-    __builtin_amdgcn_wave_barrier();
-
-    half8 pre[kDepth][2];
-    auto fetch = [&](int i, half8 (&dst)[2]) {
-        const _Float16* src = reinterpret_cast<const _Float16*>(kbase[wave][i]) + (size_t)tok * S * S + n * S + 8 * g;
-        dst[0] = *as_global<half8>(src);
-        dst[1] = *as_global<half8>(src + 16);
-    };
-#pragma unroll
-    for (int d = 0; d < kDepth; ++d)
-        if (d < nk) fetch(d, pre[d]);
-
-    for (int i0 = 0; i0 < nk; i0 += kDepth) {
-#pragma unroll
-      for (int d = 0; d < kDepth; ++d) {
-        const int ki = i0 + d;
-        if (ki >= nk) break;
-        floatx16 c[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            c[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][0], wm[nt][0], floatx16{0}, 0, 0, 0);
-            c[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][1], wm[nt][1], c[nt], 0, 0, 0);
-        }
-        if (ki + kDepth < nk) fetch(ki + kDepth, pre[d]);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            // C/D -> B layout, then the fp16 hi / lo split
-            half8 bhi[2], blo[2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = c[nt][4 * (2 * ks) + r], y = c[nt][4 * (2 * ks + 1) + r];
-                    swap32(x, y);                               // x: row 16ks + 8g + r, y: row 16ks + 8g + 4 + r
-                    const _Float16 xh = (_Float16)x, yh = (_Float16)y;
-                    bhi[ks][r] = xh;
-                    bhi[ks][4 + r] = yh;
-                    blo[ks][r] = (_Float16)(x - (float)xh);
-                    blo[ks][4 + r] = (_Float16)(y - (float)yh);
-                }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                floatx16 o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[mt][0], bhi[0], floatx16{0}, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[mt][1], bhi[1], o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[mt][0], blo[0], o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[mt][1], blo[1], o, 0, 0, 0);
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[mt][nt][v] += fmaxf(o[v], 0.f);
-            }
-        }
-      }
-    }
-    // element i = (mt, nt, v)
-    wg_reduce_flush(red, wave, [&](int i) { return acc[i >> 5][(i >> 4) & 1][i & 15]; },
-                    [&](int i, float v) { acc[i >> 5][(i >> 4) & 1][i & 15] += v; },
-                    [&](int i) { return (32 * (i >> 5) + 8 * ((i & 15) >> 2) + 4 * g + (i & 3)) * O + 32 * ((i >> 4) & 1) + n; },
-                    L.out + (size_t)tok * O * O, L.inv_n);
-}
-
 // side == out_side: out[t][i] += sum over this chunk's keys of max(plane[t][i], 0) / N.
 // A wave owns 64 consecutive 16-byte pieces of one token plane; kBatch keys are in flight per
 // lane; the partial sums are transposed through a wave-private LDS tile so that the final
@@ -592,9 +474,7 @@ hipError_t launch_finalize_up(const FinLaunch& L, int side, int acc_dtype, int m
 {
     dim3 grid(L.tokens, L.n_chunks);
     *grid_out = grid.x * grid.y;
-    if (side == 32 && acc_dtype == 0 && mfma_ok == 2) {
-        hipLaunchKernelGGL(finalize_up32_mfma2_kernel, grid, dim3(256), 0, stream, L);
-    } else if (side == 32 && acc_dtype == 0 && mfma_ok) {
+    if (side == 32 && acc_dtype == 0 && mfma_ok) {
         hipLaunchKernelGGL(finalize_up32_mfma_kernel, grid, dim3(256), 0, stream, L);
     } else if (side == 32) {
         if (acc_dtype == 0) hipLaunchKernelGGL((finalize_up_kernel<_Float16, 32>), grid, dim3(256), 0, stream, L);

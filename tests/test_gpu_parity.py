@@ -151,13 +151,12 @@ def test_tap_probs_bit_exact(dt):
 
 @pytest.mark.parametrize('sides', [(64,), (32,), (16, 32, 64), (128, 64), (8,), (24, 48)])
 @pytest.mark.parametrize('acc', ['float16', 'float32'])
-@pytest.mark.parametrize('path', ['default', 'mfma_x_only', 'no_mfma', 'general'])
+@pytest.mark.parametrize('path', ['default', 'no_mfma', 'general'])
 def test_finalize_vs_oracle(sides, acc, path, monkeypatch):
     """bicubic (A=-0.75, border-clamped taps) -> clamp -> mean over keys, incl. the x0.5
     down-sample of SDXL-2048 (128 -> 64) and the 96x96 output of 768-px models."""
-    # default: both bicubic passes on MFMA for fp16 32 -> 64; mfma_x_only: MFMA x pass + VALU y pass; no_mfma: the LDS / packed-f32 kernel; general: the any-size kernel
+    # default: MFMA x-pass for fp16 32 -> 64; no_mfma: the LDS / packed-f32 kernel; general: the any-size kernel
     monkeypatch.setenv('DAAM_NO_MFMA_FINALIZE', '1' if path == 'no_mfma' else '0')
-    monkeypatch.setenv('DAAM_FINALIZE_MFMA', '1' if path == 'mfma_x_only' else '2')
     monkeypatch.setenv('DAAM_FORCE_GENERIC', '1' if path == 'general' else '0')
     rng = np.random.default_rng(len(sides) * 31 + sides[0])
     out_side = 96 if 24 in sides else 64
