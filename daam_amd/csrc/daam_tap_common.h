@@ -140,7 +140,7 @@ __device__ __forceinline__ void softmax_accumulate(const floatx16& c0, const flo
             sa += sb;
             float sum = sa[0] + sa[1];
             sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.0f / sum;
+            const float inv = __builtin_amdgcn_rcpf(sum);                  // v_rcp_f32: 1 ulp
 #pragma unroll
             for (int i = 0; i < kSlots / 2; ++i) {
                 const half2v ph = cvt_pk_rne(ev[i] * inv);                // probs.to(dtype)

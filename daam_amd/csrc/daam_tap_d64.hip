@@ -64,12 +64,18 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
 {
     using P2 = typename Pair<ACC_T>::T;
     if constexpr (FAST_EXP) {
-        // see softmax_accumulate() in daam_tap_common.h for the error analysis of this path
+        // see softmax_accumulate() in daam_tap_common.h for the error analysis of this path.
+        // When scale is a power of two (head_dim 64: 1/8) the multiply commutes with the fp16 rounding
+        // (fp16(c) * 2^k == fp16(c * 2^k) unless the result is an fp16 subnormal, |logit| < 6.1e-5,
+        // where the two differ by < 6e-8 absolute): the logits stay unscaled in fp16 and the scale
+        // is folded into the exponent FMA.
+        const bool pow2 = (__float_as_uint(lay.scale) & 0x007fffffu) == 0;
+        const float pre = pow2 ? 1.0f : lay.scale;
         half2v xh[kSlots16 / 2];
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
-            xh[2 * mt] = cvt_pk_rne(float2v{c[mt][0], c[mt][1]} * lay.scale);
-            xh[2 * mt + 1] = cvt_pk_rne(float2v{c[mt][2], c[mt][3]} * lay.scale);
+            xh[2 * mt] = cvt_pk_rne(float2v{c[mt][0], c[mt][1]} * pre);
+            xh[2 * mt + 1] = cvt_pk_rne(float2v{c[mt][2], c[mt][3]} * pre);
         }
         if (h == 3) {                                                   // tokens 77, 78, 79
             const _Float16 ninf = -(_Float16)__builtin_inff();
@@ -84,7 +90,7 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
         }
         ma = pk_max(ma, mb);
         const float m = quad_max(fmaxf((float)ma[0], (float)ma[1]));
-        const float L = 1.44269502162933349609375f;
+        const float L = 1.44269502162933349609375f * (pow2 ? lay.scale : 1.0f);   // exact: power-of-two factor
         const float nmL = -m * L;
         float2v ev[kSlots16 / 2];
         float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
@@ -98,7 +104,7 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
             sb += ev[i + 1];
         }
         sa += sb;
-        const float inv = 1.0f / quad_sum(sa[0] + sa[1]);
+        const float inv = __builtin_amdgcn_rcpf(quad_sum(sa[0] + sa[1]));       // v_rcp_f32: 1 ulp
 #pragma unroll
         for (int i = 0; i < kSlots16 / 2; ++i) {
             const half2v ph = cvt_pk_rne(ev[i] * inv);                    // probs.to(dtype)
