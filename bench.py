@@ -97,9 +97,11 @@ def tap_bytes(layers, steps_per_launch, acc_bytes, fresh):
     return steps_per_launch * qk + acc * (1 if fresh else 2), qk, acc
 
 
-def measure_tap_kernel(eng, calls, defer, reps):
+def measure_tap_kernel(eng, calls, defer, reps, fresh):
     """HIP-event time of the tap kernel: libdaam_hip brackets its kernel launch(es) with events on
-    the launch stream (daam_profile_enable), the table upload in front of them is outside."""
+    the launch stream (daam_profile_enable), the table upload in front of them is outside.
+    ``fresh``: the launch is the first after clear() (a generation that fits one launch): the running
+    sums are written without being read, exactly as in the timed region."""
     import ctypes
     from daam_amd import _native as nat
     stream = torch.cuda.current_stream()
@@ -107,6 +109,8 @@ def measure_tap_kernel(eng, calls, defer, reps):
     nat.check(eng.lib.daam_profile_enable(eng.ctx, 1))
     times = []
     for r in range(reps + 2):
+        if fresh:
+            eng.clear()
         for s in range(defer):
             for a in calls[(r * defer + s) % len(calls)]:
                 eng.tap_qk(*a)
@@ -195,10 +199,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='sdxl1024', choices=sorted(WORKLOADS))
     ap.add_argument('--denoise-steps', type=int, default=50)
-    ap.add_argument('--defer', type=int, default=int(os.environ.get('DAAM_DEFER_STEPS', '16')),
+    ap.add_argument('--defer', type=int, default=int(os.environ.get('DAAM_DEFER_STEPS', '64')),
                     help='denoising steps tapped per launch (0 = one launch per layer call)')
     ap.add_argument('--accumulate', default='exact', choices=['exact', 'float32'])
-    ap.add_argument('--pool', type=int, default=8, help='distinct synthetic Q/K step sets resident in HBM')
+    ap.add_argument('--pool', type=int, default=0,
+                    help='distinct synthetic Q/K step sets resident in HBM (0 = one per denoising step: no step of a '
+                         'generation re-reads data an earlier one left in L2 / Infinity Cache)')
     ap.add_argument('--no-baselines', action='store_true', help='skip the CPU / eager-GPU reference timings')
     args = ap.parse_args()
 
@@ -221,7 +227,8 @@ def main():
     wl = WORKLOADS[args.workload]
     layers = topology(wl['kind'], wl['latent'])
     latent_side = 64
-    sets = make_inputs(layers, args.pool, device, seed=1234 + rank)
+    pool = args.pool if args.pool > 0 else args.denoise_steps
+    sets = make_inputs(layers, pool, device, seed=1234 + rank)
     eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=args.accumulate, defer_steps=args.defer)
 
     calls = call_lists(layers, sets, latent_side)
@@ -252,12 +259,16 @@ def main():
     out = None
     if rank == 0:
         acc_bytes = 2 if args.accumulate == 'exact' else 4
-        spl = max(1, args.defer)
+        # steps one tap launch covers: the step window, or fewer when the recorded Q / K reach the engine's
+        # byte budget (a launch is then forced at the next step boundary)
+        step_bytes = sum(q.numel() * q.element_size() + k.numel() * k.element_size() for q, k in sets[0])
+        spl = max(1, min(args.defer, args.denoise_steps, 64, -(-eng.defer_bytes // step_bytes)))
         # ---- roofline of the dominant kernel (tap) ---------------------------------------------
         if args.defer > 0:
-            tap_ms = measure_tap_kernel(eng, calls, args.defer, reps=10)
-            bytes_launch, qk_bytes, acc_total = tap_bytes(layers, spl, acc_bytes, fresh=False)
             launches_per_gen = -(-args.denoise_steps // spl)
+            fresh = launches_per_gen == 1
+            tap_ms = measure_tap_kernel(eng, calls, spl, reps=10, fresh=fresh)
+            bytes_launch, qk_bytes, acc_total = tap_bytes(layers, spl, acc_bytes, fresh=fresh)
         else:
             # immediate mode: 1 launch per layer call; time a whole denoising step of launches
             stream = torch.cuda.current_stream()
@@ -275,12 +286,12 @@ def main():
             bytes_launch /= len(layers)
             launches_per_gen = args.denoise_steps * len(layers)
         achieved = bytes_launch / (tap_ms * 1e-3) / 1e9
-        survey_bytes = spl * (qk_bytes + 2 * acc_total) if args.defer > 0 else bytes_launch
+        survey_bytes = spl * (qk_bytes + 2 * acc_total) if args.defer > 0 else bytes_launch   # RMW per step
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
             try:
-                rec = json.load(open(tpath)).get(f'{args.workload}:defer{args.defer}:{args.accumulate}')
+                rec = json.load(open(tpath)).get(f'{args.workload}:defer{spl}:{args.accumulate}')
                 traffic = rec.get('tap_bytes_per_launch') if rec else None
             except Exception:
                 traffic = None
@@ -329,7 +340,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': f'{wl["label"]}, {args.denoise_steps} denoising steps, 77 tokens, CFG batch 2, fp16 Q/K',
-                       'accumulate': args.accumulate, 'defer_steps': args.defer, 'parallelism': f'prompt-shard x{world}',
+                       'accumulate': args.accumulate, 'defer_steps': spl, 'parallelism': f'prompt-shard x{world}',
                        'generations_per_rank': args.steps},
             'roofline': roofline, 'cpu_baseline': cpu,
         }

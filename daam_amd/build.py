@@ -27,7 +27,35 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def fastpath_out() -> str:
+    import sysconfig
+    return os.path.join(HERE, '_fastpath' + sysconfig.get_config_var('EXT_SUFFIX'))
+
+
+def build_fastpath(force: bool = False, verbose: bool = True) -> str:
+    """``daam_amd._fastpath``: the host-side tap recorder (csrc/daam_fastpath.cpp), a CPython extension
+    compiled against the torch headers of the running interpreter (host code only, no device code)."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ext
+    src = os.path.join(HERE, 'csrc', 'daam_fastpath.cpp')
+    out = fastpath_out()
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    lib_dirs = ext.library_paths()
+    cmd = ['g++', '-O2', '-std=c++17', '-fPIC', '-shared',
+           f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}',
+           '-I' + sysconfig.get_paths()['include'], *['-I' + p for p in ext.include_paths()],
+           src, '-o', out, *['-L' + p for p in lib_dirs], *['-Wl,-rpath,' + p for p in lib_dirs],
+           '-ltorch_python', '-ltorch', '-ltorch_cpu', '-lc10']
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
+    build_fastpath(force, verbose)
     if not force and not stale():
         return OUT
     cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',

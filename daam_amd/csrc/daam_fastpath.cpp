@@ -1,0 +1,309 @@
+// daam_amd._fastpath -- host-side recorder of deferred taps (CPython extension, no pybind).
+//
+// The attention processor calls HeatMapEngine.tap_qk once per cross-attention layer per denoising
+// step: 3000 calls per 50-step SDXL generation (reference: the body of
+// UNetCrossAttentionHooker.__call__, daam/trace.py:285-294).  In deferred mode a call only has to
+// (1) check that the layer's Q / K look like they did when the layer's DaamQKDesc was built and
+// (2) remember two device pointers and keep the tensors alive until the launch.  Done in Python that
+// is ~0.6 us per call, as much as the GPU needs for the tap itself; here it is one METH_FASTCALL
+// function that reads the at::Tensor fields directly.  Everything that is not the steady state
+// (first call of a layer, shape / dtype change, non-contiguous input, window full) is handed back to
+// the Python engine through callbacks, so the validation logic and error messages live in one place
+// (daam_amd/engine.py).  No device work and no libdaam_hip calls happen here: the engine passes the
+// recorded arrays to daam_tap_qk_enqueue_many (include/daam_hip.h) at flush time.
+#include <Python.h>
+#include <torch/csrc/autograd/python_variable.h>
+#include <ATen/core/Tensor.h>
+
+#include <climits>
+#include <cstdint>
+#include <vector>
+
+namespace {
+
+struct LayerCache {
+    bool valid = false;
+    int64_t q_size[3] = {0, 0, 0};
+    int64_t k_size[3] = {0, 0, 0};
+    int dtype = -1;              // c10::ScalarType
+    int device_type = -1;        // c10::DeviceType of the validated call (the engine only admits HIP devices)
+    int device = -1;
+    long heads = 0, factor = 0;
+    int round_logits = 1;
+    double scale = 0.0;
+    uint64_t desc = 0;           // address of the layer's DaamQKDesc (owned by the engine)
+};
+
+struct Recorder {
+    PyObject_HEAD
+    std::vector<LayerCache>* cache;
+    std::vector<int32_t>* cnt;          // recorded steps per layer
+    std::vector<uint8_t>* touched;      // engine._touch(layer) already called since clear()
+    std::vector<int32_t>* layers;       // parallel arrays handed to daam_tap_qk_enqueue_many
+    std::vector<uint64_t>* qp;
+    std::vector<uint64_t>* kp;
+    std::vector<uint64_t>* dp;
+    std::vector<at::Tensor>* keep;      // Q / K of the recorded taps stay alive until drop()
+    int window;                         // steps of one layer per launch
+    int64_t budget;                     // bytes of recorded Q / K kept alive before a launch is forced
+    int64_t held;                       // bytes of Q / K currently recorded
+    PyObject* slow_cb;                  // engine._tap_qk_slow(layer, q, k, heads, scale, factor, round_logits)
+    PyObject* flush_cb;                 // engine.flush()
+    PyObject* touch_cb;                 // engine._touch(layer)
+};
+
+int Recorder_init(Recorder* self, PyObject* args, PyObject* kw) {
+    static const char* names[] = {"n_layers", "slow", "flush", "touch", nullptr};
+    int n = 0;
+    PyObject *slow, *flush, *touch;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "iOOO", const_cast<char**>(names), &n, &slow, &flush, &touch)) return -1;
+    if (n < 0) { PyErr_SetString(PyExc_ValueError, "n_layers < 0"); return -1; }
+    self->cache = new std::vector<LayerCache>(n);
+    self->cnt = new std::vector<int32_t>(n, 0);
+    self->touched = new std::vector<uint8_t>(n, 0);
+    self->layers = new std::vector<int32_t>();
+    self->qp = new std::vector<uint64_t>();
+    self->kp = new std::vector<uint64_t>();
+    self->dp = new std::vector<uint64_t>();
+    self->keep = new std::vector<at::Tensor>();
+    self->window = 1;
+    self->budget = INT64_MAX;
+    self->held = 0;
+    Py_INCREF(slow); Py_INCREF(flush); Py_INCREF(touch);
+    self->slow_cb = slow; self->flush_cb = flush; self->touch_cb = touch;
+    return 0;
+}
+
+int Recorder_traverse(Recorder* self, visitproc visit, void* arg) {
+    Py_VISIT(self->slow_cb); Py_VISIT(self->flush_cb); Py_VISIT(self->touch_cb);
+    return 0;
+}
+
+int Recorder_clear(Recorder* self) {
+    Py_CLEAR(self->slow_cb); Py_CLEAR(self->flush_cb); Py_CLEAR(self->touch_cb);
+    return 0;
+}
+
+void Recorder_dealloc(Recorder* self) {
+    PyObject_GC_UnTrack(self);
+    delete self->cache; delete self->cnt; delete self->touched; delete self->layers;
+    delete self->qp; delete self->kp; delete self->dp; delete self->keep;
+    Py_XDECREF(self->slow_cb); Py_XDECREF(self->flush_cb); Py_XDECREF(self->touch_cb);
+    Py_TYPE(self)->tp_free(reinterpret_cast<PyObject*>(self));
+}
+
+inline bool same3(const at::Tensor& t, const int64_t (&s)[3]) {
+    if (t.dim() != 3) return false;
+    const auto sz = t.sizes();
+    return sz[0] == s[0] && sz[1] == s[1] && sz[2] == s[2];
+}
+
+inline bool same_device(const at::Tensor& t, const LayerCache& c) {
+    const auto d = t.device();
+    return static_cast<int>(d.type()) == c.device_type && static_cast<int>(d.index()) == c.device;
+}
+
+// A launch is due before recording a tap of `layer` when the layer's step window is full, or -- checked
+// on step boundaries only (the layer that opened this window comes round again) -- when the recorded
+// Q / K have reached the byte budget.
+inline bool must_launch(const Recorder* self, long layer) {
+    if ((*self->cnt)[layer] >= self->window) return true;
+    return self->held >= self->budget && !self->layers->empty() && (*self->layers)[0] == layer;
+}
+
+inline void push(Recorder* self, int layer, const at::Tensor& q, const at::Tensor& k, uint64_t desc) {
+    self->layers->push_back(layer);
+    self->qp->push_back(reinterpret_cast<uint64_t>(q.data_ptr()));
+    self->kp->push_back(reinterpret_cast<uint64_t>(k.data_ptr()));
+    self->dp->push_back(desc);
+    self->keep->push_back(q);
+    self->keep->push_back(k);
+    self->held += static_cast<int64_t>(q.nbytes()) + static_cast<int64_t>(k.nbytes());
+    (*self->cnt)[layer] += 1;
+}
+
+// tap(layer, query, key, heads, scale, factor, round_logits=True) -> None
+PyObject* Recorder_tap(Recorder* self, PyObject* const* args, Py_ssize_t nargs, PyObject* kwnames) {
+    const bool has_kw = kwnames != nullptr && PyTuple_GET_SIZE(kwnames) > 0;
+    if (!has_kw && (nargs == 6 || nargs == 7) && THPVariable_Check(args[1]) && THPVariable_Check(args[2])) {
+        const long layer = PyLong_AsLong(args[0]);
+        const long heads = PyLong_AsLong(args[3]);
+        const double scale = PyFloat_AsDouble(args[4]);
+        const long factor = PyLong_AsLong(args[5]);
+        const int rl = nargs == 7 ? PyObject_IsTrue(args[6]) : 1;
+        if (PyErr_Occurred()) {
+            PyErr_Clear();                                   // odd argument types: let Python complain
+        } else if (layer >= 0 && layer < static_cast<long>(self->cache->size())) {
+            const LayerCache& c = (*self->cache)[layer];
+            const at::Tensor& q = THPVariable_Unpack(args[1]);
+            const at::Tensor& k = THPVariable_Unpack(args[2]);
+            if (c.valid && same3(q, c.q_size) && same3(k, c.k_size) &&
+                static_cast<int>(q.scalar_type()) == c.dtype && static_cast<int>(k.scalar_type()) == c.dtype &&
+                same_device(q, c) && same_device(k, c) &&
+                heads == c.heads && factor == c.factor && scale == c.scale && rl == c.round_logits &&
+                q.is_contiguous() && k.is_contiguous()) {
+                if (!self->flush_cb || !self->touch_cb) { PyErr_SetString(PyExc_RuntimeError, "recorder is closed"); return nullptr; }
+                if (must_launch(self, layer)) {
+                    PyObject* r = PyObject_CallNoArgs(self->flush_cb);     // launches, then calls drop()
+                    if (!r) return nullptr;
+                    Py_DECREF(r);
+                }
+                push(self, static_cast<int>(layer), q, k, c.desc);
+                if (!(*self->touched)[layer]) {
+                    PyObject* r = PyObject_CallOneArg(self->touch_cb, args[0]);
+                    if (!r) return nullptr;
+                    Py_DECREF(r);
+                    (*self->touched)[layer] = 1;
+                }
+                Py_RETURN_NONE;
+            }
+        }
+    }
+    if (!self->slow_cb) { PyErr_SetString(PyExc_RuntimeError, "recorder is closed"); return nullptr; }
+    return PyObject_Vectorcall(self->slow_cb, args, nargs, kwnames);
+}
+
+// set_cache(layer, query, key, heads, scale, factor, round_logits, desc_addr)
+PyObject* Recorder_set_cache(Recorder* self, PyObject* args) {
+    int layer, rl;
+    long heads, factor;
+    double scale;
+    unsigned long long desc;
+    PyObject *qo, *ko;
+    if (!PyArg_ParseTuple(args, "iOOldlpK", &layer, &qo, &ko, &heads, &scale, &factor, &rl, &desc)) return nullptr;
+    if (layer < 0 || layer >= static_cast<int>(self->cache->size()) || !THPVariable_Check(qo) || !THPVariable_Check(ko)) {
+        PyErr_SetString(PyExc_ValueError, "set_cache: bad layer or tensors");
+        return nullptr;
+    }
+    const at::Tensor& q = THPVariable_Unpack(qo);
+    const at::Tensor& k = THPVariable_Unpack(ko);
+    if (q.dim() != 3 || k.dim() != 3) { PyErr_SetString(PyExc_ValueError, "set_cache: query / key must be 3-d"); return nullptr; }
+    LayerCache& c = (*self->cache)[layer];
+    for (int i = 0; i < 3; ++i) { c.q_size[i] = q.sizes()[i]; c.k_size[i] = k.sizes()[i]; }
+    c.dtype = static_cast<int>(q.scalar_type());
+    c.device_type = static_cast<int>(q.device().type());
+    c.device = static_cast<int>(q.device().index());
+    c.heads = heads; c.factor = factor; c.scale = scale; c.round_logits = rl; c.desc = desc;
+    c.valid = true;
+    Py_RETURN_NONE;
+}
+
+// record(layer, query, key, desc_addr): unconditional (the engine validated the call)
+PyObject* Recorder_record(Recorder* self, PyObject* args) {
+    int layer;
+    unsigned long long desc;
+    PyObject *qo, *ko;
+    if (!PyArg_ParseTuple(args, "iOOK", &layer, &qo, &ko, &desc)) return nullptr;
+    if (layer < 0 || layer >= static_cast<int>(self->cache->size()) || !THPVariable_Check(qo) || !THPVariable_Check(ko)) {
+        PyErr_SetString(PyExc_ValueError, "record: bad layer or tensors");
+        return nullptr;
+    }
+    push(self, layer, THPVariable_Unpack(qo), THPVariable_Unpack(ko), desc);
+    Py_RETURN_NONE;
+}
+
+PyObject* Recorder_pending(Recorder* self, PyObject* arg) {            // recorded steps of one layer
+    const long layer = PyLong_AsLong(arg);
+    if (layer == -1 && PyErr_Occurred()) return nullptr;
+    if (layer < 0 || layer >= static_cast<long>(self->cnt->size())) return PyLong_FromLong(0);
+    return PyLong_FromLong((*self->cnt)[layer]);
+}
+
+PyObject* Recorder_count(Recorder* self, PyObject*) { return PyLong_FromSize_t(self->layers->size()); }
+
+// buffers() -> (n, layers_addr, q_addr, k_addr, desc_addr): valid until the next record / drop
+PyObject* Recorder_buffers(Recorder* self, PyObject*) {
+    return Py_BuildValue("(nKKKK)", static_cast<Py_ssize_t>(self->layers->size()),
+                         static_cast<unsigned long long>(reinterpret_cast<uintptr_t>(self->layers->data())),
+                         static_cast<unsigned long long>(reinterpret_cast<uintptr_t>(self->qp->data())),
+                         static_cast<unsigned long long>(reinterpret_cast<uintptr_t>(self->kp->data())),
+                         static_cast<unsigned long long>(reinterpret_cast<uintptr_t>(self->dp->data())));
+}
+
+PyObject* Recorder_drop(Recorder* self, PyObject*) {                   // forget the recorded taps
+    self->layers->clear(); self->qp->clear(); self->kp->clear(); self->dp->clear();
+    self->keep->clear();
+    self->held = 0;
+    std::fill(self->cnt->begin(), self->cnt->end(), 0);
+    Py_RETURN_NONE;
+}
+
+PyObject* Recorder_reset_touched(Recorder* self, PyObject*) {
+    std::fill(self->touched->begin(), self->touched->end(), 0);
+    Py_RETURN_NONE;
+}
+
+PyObject* Recorder_invalidate(Recorder* self, PyObject*) {             // forget every layer's cached call shape
+    for (auto& c : *self->cache) c.valid = false;
+    Py_RETURN_NONE;
+}
+
+PyObject* Recorder_set_window(Recorder* self, PyObject* arg) {
+    const long w = PyLong_AsLong(arg);
+    if (w == -1 && PyErr_Occurred()) return nullptr;
+    self->window = static_cast<int>(w < 1 ? 1 : w);
+    Py_RETURN_NONE;
+}
+
+PyObject* Recorder_get_window(Recorder* self, PyObject*) { return PyLong_FromLong(self->window); }
+
+PyObject* Recorder_set_budget(Recorder* self, PyObject* arg) {
+    const long long b = PyLong_AsLongLong(arg);
+    if (b == -1 && PyErr_Occurred()) return nullptr;
+    self->budget = b <= 0 ? INT64_MAX : b;
+    Py_RETURN_NONE;
+}
+
+PyObject* Recorder_full(Recorder* self, PyObject* arg) {               // would tap(layer) launch first?
+    const long layer = PyLong_AsLong(arg);
+    if (layer == -1 && PyErr_Occurred()) return nullptr;
+    return PyBool_FromLong(layer >= 0 && layer < static_cast<long>(self->cnt->size()) && must_launch(self, layer));
+}
+
+PyObject* Recorder_held_bytes(Recorder* self, PyObject*) { return PyLong_FromLongLong(self->held); }
+
+PyMethodDef Recorder_methods[] = {
+    {"tap", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(Recorder_tap)), METH_FASTCALL | METH_KEYWORDS,
+     "tap(layer, query, key, heads, scale, factor, round_logits=True): record one deferred tap"},
+    {"set_cache", reinterpret_cast<PyCFunction>(Recorder_set_cache), METH_VARARGS, "remember a layer's validated call shape"},
+    {"record", reinterpret_cast<PyCFunction>(Recorder_record), METH_VARARGS, "record a tap the engine validated"},
+    {"pending", reinterpret_cast<PyCFunction>(Recorder_pending), METH_O, "recorded steps of one layer"},
+    {"count", reinterpret_cast<PyCFunction>(Recorder_count), METH_NOARGS, "recorded taps"},
+    {"buffers", reinterpret_cast<PyCFunction>(Recorder_buffers), METH_NOARGS, "(n, layers, q, k, desc) host addresses"},
+    {"drop", reinterpret_cast<PyCFunction>(Recorder_drop), METH_NOARGS, "forget the recorded taps"},
+    {"reset_touched", reinterpret_cast<PyCFunction>(Recorder_reset_touched), METH_NOARGS, ""},
+    {"invalidate", reinterpret_cast<PyCFunction>(Recorder_invalidate), METH_NOARGS, ""},
+    {"set_window", reinterpret_cast<PyCFunction>(Recorder_set_window), METH_O, "steps per layer before tap() asks for a flush"},
+    {"get_window", reinterpret_cast<PyCFunction>(Recorder_get_window), METH_NOARGS, ""},
+    {"set_budget", reinterpret_cast<PyCFunction>(Recorder_set_budget), METH_O, "bytes of recorded Q / K before tap() asks for a flush"},
+    {"full", reinterpret_cast<PyCFunction>(Recorder_full), METH_O, "would tap(layer) launch before recording?"},
+    {"held_bytes", reinterpret_cast<PyCFunction>(Recorder_held_bytes), METH_NOARGS, ""},
+    {nullptr, nullptr, 0, nullptr}};
+
+PyTypeObject RecorderType = {PyVarObject_HEAD_INIT(nullptr, 0)};
+
+PyModuleDef module_def = {PyModuleDef_HEAD_INIT, "_fastpath", "host-side recorder of deferred DAAM taps", -1, nullptr};
+
+}  // namespace
+
+PyMODINIT_FUNC PyInit__fastpath(void) {
+    RecorderType.tp_name = "daam_amd._fastpath.Recorder";
+    RecorderType.tp_basicsize = sizeof(Recorder);
+    RecorderType.tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_GC;     // engine <-> recorder callbacks form a cycle
+    RecorderType.tp_traverse = reinterpret_cast<traverseproc>(Recorder_traverse);
+    RecorderType.tp_clear = reinterpret_cast<inquiry>(Recorder_clear);
+    RecorderType.tp_new = PyType_GenericNew;
+    RecorderType.tp_init = reinterpret_cast<initproc>(Recorder_init);
+    RecorderType.tp_dealloc = reinterpret_cast<destructor>(Recorder_dealloc);
+    RecorderType.tp_methods = Recorder_methods;
+    if (PyType_Ready(&RecorderType) < 0) return nullptr;
+    PyObject* m = PyModule_Create(&module_def);
+    if (!m) return nullptr;
+    Py_INCREF(&RecorderType);
+    if (PyModule_AddObject(m, "Recorder", reinterpret_cast<PyObject*>(&RecorderType)) < 0) {
+        Py_DECREF(&RecorderType);
+        Py_DECREF(m);
+        return nullptr;
+    }
+    return m;
+}

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -22,11 +23,13 @@ Key = Tuple[int, int, int]   # (factor, layer, head) -- daam/heatmap.py:145
 
 class HeatMapEngine:
     def __init__(self, n_layers: int, tokens: int = 77, out_side: int = 64, accumulate: str = 'exact',
-                 defer_steps: int = 0):
+                 defer_steps: int = 0, defer_bytes: int = 32 << 30):
         """``accumulate``: ``'exact'`` keeps the running sums in the pipeline dtype like the
         reference (fp16 sums on an fp16 pipeline, heatmap.py:156); ``'float32'`` is the
         accuracy mode.  ``defer_steps`` > 0 records Q/K pointers and taps ``defer_steps``
-        denoising steps of all layers in one launch."""
+        denoising steps of all layers in one launch (at most 64); the Q / K of the recorded steps stay
+        alive until then, and a launch is forced at the next step boundary once they add up to
+        ``defer_bytes`` (both CFG halves count: 388 MB per SDXL-1024 step)."""
         if accumulate not in ('exact', 'float32'):
             raise ValueError("accumulate must be 'exact' or 'float32'")
         self.lib = nat.load()
@@ -35,6 +38,8 @@ class HeatMapEngine:
         self.out_side = int(out_side)
         self.accumulate = accumulate
         self.defer_steps = min(int(defer_steps), 64)     # the kernels stage at most 64 steps of pointers per launch
+        self.defer_bytes = int(defer_bytes) if defer_bytes and defer_bytes > 0 else 1 << 62
+        self._held = 0                                    # bytes of recorded Q / K (Python recorder)
         self.ctx: Optional[nat.c_void_p] = None
         self.device: Optional[torch.device] = None
         self.acc_dtype: Optional[torch.dtype] = None
@@ -43,12 +48,27 @@ class HeatMapEngine:
         self.touched: List[int] = []                     # layers updated since clear(), first-update order
         # deferred taps: recorded per call (the tensors are kept alive until the flush)
         self._rec: List[tuple] = []                      # (layer, query, key, address of its DaamQKDesc)
-        # steps per launch: the first launch after clear() is kept short (the GPU has nothing else to
-        # do while the host records the first window), later ones use the full defer_steps
+        # steps per launch; $DAAM_FIRST_WINDOW shortens the first launch after clear() (an experiment knob:
+        # it lets the GPU start while a slow host is still recording, at the price of one more launch)
         self._window = self._first_window()
         self._cnt: List[int] = [0] * self.n_layers      # recorded steps per layer
         self._qk_cache: List[Optional[tuple]] = [None] * self.n_layers
         self._touched_flag: List[bool] = [False] * self.n_layers
+        # deferred mode: the per-call bookkeeping runs in the C++ recorder (csrc/daam_fastpath.cpp) when
+        # that extension is built; the Python implementation below is the same logic and stays the
+        # slow path (first call of a layer, shape changes) and the fallback.  Both only record host-side
+        # pointers -- all arithmetic is in libdaam_hip either way.
+        self._fast = None
+        if self.defer_steps and not os.environ.get('DAAM_NO_FASTPATH'):
+            try:
+                from . import _fastpath
+            except ImportError:
+                _fastpath = None
+            if _fastpath is not None:
+                self._fast = _fastpath.Recorder(self.n_layers, self._tap_qk_slow, self.flush, self._touch)
+                self._fast.set_window(self._window)
+                self._fast.set_budget(self.defer_bytes)
+                self.tap_qk = self._fast.tap
 
     # ---- lifetime --------------------------------------------------------------------------
     def _require_device(self, t: torch.Tensor) -> None:
@@ -83,6 +103,8 @@ class HeatMapEngine:
         self.touched.clear()
         self._touched_flag = [False] * self.n_layers
         self._qk_cache = [None] * self.n_layers
+        if self._fast is not None:
+            self._fast.invalidate()
         self._drop_recorded()
 
     def __del__(self):
@@ -117,7 +139,9 @@ class HeatMapEngine:
         self._drop_recorded()
         self.touched.clear()
         self._touched_flag = [False] * self.n_layers
-        self._window = self._first_window()
+        self._set_window(self._first_window())
+        if self._fast is not None:
+            self._fast.reset_touched()
         if self.ctx is not None:
             nat.check(self.lib.daam_reset(self.ctx, self.stream))
 
@@ -143,10 +167,11 @@ class HeatMapEngine:
         if self.defer_steps:
             # record only: pointers cross the FFI in one daam_tap_qk_enqueue_many call per flush
             n = cnt[layer]
-            if n >= self._window:
+            if n >= self._window or (self._held >= self.defer_bytes and self._rec[0][0] == layer):
                 self.flush()
                 n = 0
             cnt[layer] = n + 1
+            self._held += c[12]
             self._rec.append((layer, query, key, c[9]))
         else:
             rc = self.lib.daam_tap_qk(self.ctx, layer, query.data_ptr(), key.data_ptr(), c[7], self.stream)
@@ -154,6 +179,37 @@ class HeatMapEngine:
                 nat.check(rc)
         if not self._touched_flag[layer]:
             self._touch(layer)
+
+    def _tap_qk_slow(self, layer: int, query: torch.Tensor, key: torch.Tensor, heads: int, scale: float,
+                     factor: int, round_logits: bool = True) -> None:
+        """Called by the C++ recorder for everything but the steady state: validates, rebuilds the
+        layer's call descriptor, teaches the recorder the new call shape and records the tap."""
+        f = self._fast
+        c = self._qk_cache[layer] if 0 <= layer < self.n_layers else None
+        fresh = (c is None or c[0] != query.shape or c[1] != key.shape or c[2] is not query.dtype
+                 or key.dtype is not c[2] or c[3] != heads or c[4] != scale or c[5] != round_logits
+                 or c[6] != factor or not query.is_contiguous() or not key.is_contiguous())
+        if fresh:
+            query, key, c = self._prepare_qk(layer, query, key, heads, scale, factor, round_logits)
+        if f.full(layer):
+            self.flush()
+        if fresh:
+            f.set_cache(layer, query, key, int(heads), float(scale), int(factor), bool(round_logits), c[9])
+        f.record(layer, query, key, c[9])
+        self._touch(layer)
+
+    @property
+    def pending_taps(self) -> int:
+        """Recorded taps that have not been launched yet."""
+        return self._fast.count() if self._fast is not None else len(self._rec)
+
+    def _pending(self, layer: int) -> int:
+        return self._fast.pending(layer) if self._fast is not None else self._cnt[layer]
+
+    def _set_window(self, w: int) -> None:
+        self._window = w
+        if self._fast is not None:
+            self._fast.set_window(w)
 
     def _prepare_qk(self, layer, query, key, heads, scale, factor, round_logits):
         """Slow path of ``tap_qk``: validate, (re)configure the layer, build the call descriptor.
@@ -181,19 +237,31 @@ class HeatMapEngine:
             q_stride_b=hw * c, q_stride_h=d, q_stride_p=c,
             k_stride_b=tokens * c, k_stride_h=d, k_stride_t=c)
         # a shape change of a layer inside a deferred batch starts a new batch (the C side checks too)
-        if self._cnt[layer]:
+        if self._pending(layer):
             self.flush()
         entry = (query.shape, key.shape, query.dtype, heads, scale, round_logits, factor, nat.byref(desc), desc,
-                 ctypes.addressof(desc), query.numel(), key.numel())
+                 ctypes.addressof(desc), query.numel(), key.numel(),
+                 (query.numel() + key.numel()) * query.element_size())
         self._qk_cache[layer] = entry
         return query, key, entry
 
     def _first_window(self) -> int:
-        return max(1, min(self.defer_steps, 4)) if self.defer_steps else 0
+        return max(1, min(self.defer_steps, int(os.environ.get('DAAM_FIRST_WINDOW', 64)))) if self.defer_steps else 0
 
     def flush(self) -> None:
         """Run every recorded (deferred) tap; the held Q/K references are dropped afterwards
         (stream order keeps their memory valid until the kernel has consumed it)."""
+        if self._fast is not None:
+            n, la, qa, ka, da = self._fast.buffers()
+            if self.ctx is None or n == 0:
+                return
+            try:
+                nat.check(self.lib.daam_tap_qk_enqueue_many(self.ctx, n, la, qa, ka, da))
+                nat.check(self.lib.daam_tap_flush(self.ctx, self.stream))
+                self._set_window(self.defer_steps)
+            finally:
+                self._drop_recorded()
+            return
         rec = self._rec
         n = len(rec)
         if self.ctx is None or n == 0:
@@ -213,7 +281,10 @@ class HeatMapEngine:
 
     def _drop_recorded(self) -> None:
         self._rec.clear()
+        self._held = 0
         self._cnt[:] = [0] * self.n_layers              # in place: tap_qk holds a reference across flush()
+        if self._fast is not None:
+            self._fast.drop()
 
     def tap_probs(self, layer: int, probs: torch.Tensor, factor: int) -> None:
         """``probs`` [B*H, hw, tokens] as returned by ``get_attention_scores`` (trace.py:276)."""

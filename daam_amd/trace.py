@@ -30,7 +30,11 @@ __all__ = ['trace', 'DiffusionHeatMapHooker', 'GlobalHeatMap']
 
 
 def _default_defer() -> int:
-    return int(os.environ.get('DAAM_DEFER_STEPS', '16'))
+    return int(os.environ.get('DAAM_DEFER_STEPS', '64'))
+
+
+def _default_defer_bytes() -> int:
+    return int(os.environ.get('DAAM_DEFER_BYTES', str(32 << 30)))
 
 
 class DiffusionHeatMapHooker(AggregateHooker):
@@ -41,7 +45,10 @@ class DiffusionHeatMapHooker(AggregateHooker):
         ``accumulate`` = ``'exact'`` (running sums in the pipeline dtype, like the reference) or
         ``'float32'``; ``tap`` = ``'qk'`` (fused, default) or ``'probs'`` (materialised
         probabilities, bit-identical adds); ``defer_steps`` = denoising steps tapped per launch
-        (0 = one launch per layer call; default ``$DAAM_DEFER_STEPS`` or 16; at most 64)."""
+        (0 = one launch per layer call; default ``$DAAM_DEFER_STEPS`` or 64, the most one launch takes).
+        The Q / K of the recorded steps are kept alive until their launch: at most ``$DAAM_DEFER_BYTES``
+        (default 32 GiB of the 288 GB; a 50-step SDXL-1024 generation holds 19.4 GB -- both CFG halves of
+        every Q -- and runs as ONE tap launch, issued when the maps are first read)."""
         if tap not in ('qk', 'probs'):
             raise ValueError("tap must be 'qk' or 'probs'")
         h = pipeline.unet.config.sample_size * pipeline.vae_scale_factor
@@ -52,7 +59,8 @@ class DiffusionHeatMapHooker(AggregateHooker):
         modules_found = self.locator.locate(pipeline.unet)
         self.engine = HeatMapEngine(max(1, len(modules_found)), tokens=77, out_side=int(math.sqrt(self.latent_hw)),
                                     accumulate=accumulate,
-                                    defer_steps=_default_defer() if defer_steps is None else defer_steps)
+                                    defer_steps=_default_defer() if defer_steps is None else defer_steps,
+                                    defer_bytes=_default_defer_bytes())
         self.all_heat_maps = RawHeatMapCollection(self.engine)
         self.last_prompt: str = ''
         self.last_image = None

@@ -192,34 +192,105 @@ def fake_engine(monkeypatch):
     return E, lib
 
 
-def test_engine_deferred_bookkeeping(fake_engine):
+@pytest.mark.parametrize('recorder', ['c++', 'python'])
+def test_engine_deferred_bookkeeping(fake_engine, monkeypatch, recorder):
     E, lib = fake_engine
+    if recorder == 'python':
+        monkeypatch.setenv('DAAM_NO_FASTPATH', '1')
     eng = E.HeatMapEngine(3, defer_steps=2)
+    assert (eng._fast is not None) == (recorder == 'c++')    # build() compiles daam_amd._fastpath
     q = [torch.zeros(2, 64, 16, dtype=torch.float16) for _ in range(3)]
     k = [torch.zeros(2, 77, 16, dtype=torch.float16) for _ in range(3)]
     for step in range(5):
         for layer in (2, 0, 1):                       # execution order != locator order
             eng.tap_qk(layer, q[layer], k[layer], heads=2, scale=0.35, factor=8 // 8 or 1)
-    # 5 steps at 2 per launch (the first window after clear() is min(defer, 4) = 2 as well): flushed after
+    # 5 steps at 2 per launch: flushed after
     # steps 2 and 4 (when step 3 / 5 arrive), 3 taps still recorded
     assert lib.names().count('daam_tap_flush') == 2
     many = [c for c in lib.calls if c[0] == 'daam_tap_qk_enqueue_many']
     assert [c[1][1] for c in many] == [6, 6]
-    assert len(eng._rec) == 3 and eng.touched == [2, 0, 1]
+    assert eng.pending_taps == 3 and eng.touched == [2, 0, 1]
     assert eng.keys()[:2] == [(1, 2, 0), (1, 2, 1)]
     list(eng.items())                                  # reading the sums flushes the rest
-    assert lib.names().count('daam_tap_flush') == 3 and not eng._rec
+    assert lib.names().count('daam_tap_flush') == 3 and not eng.pending_taps
     assert lib.names().count('daam_layer_configure') == 3
     # a shape change of a layer mid-batch starts a new batch and a new buffer
     eng.tap_qk(0, q[0], k[0], 2, 0.35, 1)
     eng.tap_qk(0, torch.zeros(2, 256, 16, dtype=torch.float16), k[0], 2, 0.35, 1)
     assert lib.names().count('daam_tap_flush') == 4 and lib.names().count('daam_layer_configure') == 4
     eng.clear()                                        # RawHeatMapCollection.clear: drop recorded taps, zero sums
-    assert not eng._rec and not eng.touched and lib.names()[-1] == 'daam_reset'
+    assert not eng.pending_taps and not eng.touched and lib.names()[-1] == 'daam_reset'
     with pytest.raises(LookupError):
         eng.global_heat_map()
     eng.close()
     assert lib.names()[-1] == 'daam_ctx_destroy'
+
+
+def test_cxx_recorder_steady_state(fake_engine):
+    """daam_amd._fastpath: positional steady-state calls never re-enter Python; anything unusual does."""
+    import ctypes
+    E, lib = fake_engine
+    eng = E.HeatMapEngine(2, defer_steps=3)
+    assert eng._fast is not None and eng.tap_qk == eng._fast.tap
+    slow = []
+    orig = eng._prepare_qk
+    eng._prepare_qk = lambda *a: (slow.append(a[0]), orig(*a))[1]
+    q = [torch.zeros(2, 64, 16, dtype=torch.float16) for _ in range(4)]
+    k = [torch.zeros(2, 77, 16, dtype=torch.float16) for _ in range(4)]
+    for step in range(3):
+        for layer in (1, 0):
+            eng.tap_qk(layer, q[2 * layer + step % 2], k[2 * layer + step % 2], 2, 0.35, 1)
+    assert slow == [1, 0] and eng.pending_taps == 6 and 'daam_tap_flush' not in lib.names()
+    n, la, qa, ka, da = eng._fast.buffers()
+    assert n == 6
+    assert list((ctypes.c_int32 * n).from_address(la)) == [1, 0, 1, 0, 1, 0]
+    assert list((ctypes.c_uint64 * n).from_address(qa)) == [q[i].data_ptr() for i in (2, 0, 3, 1, 2, 0)]
+    assert list((ctypes.c_uint64 * n).from_address(ka)) == [k[i].data_ptr() for i in (2, 0, 3, 1, 2, 0)]
+    descs = list((ctypes.c_uint64 * n).from_address(da))
+    assert descs[0] == eng._qk_cache[1][9] and descs[1] == eng._qk_cache[0][9]
+    # the window (3 steps) is full: the next call launches first
+    eng.tap_qk(1, q[2], k[2], 2, 0.35, 1)
+    assert lib.names().count('daam_tap_flush') == 1 and eng.pending_taps == 1 and slow == [1, 0]
+    # changed call parameters, a non-contiguous input, keyword arguments: all take the Python path
+    eng.tap_qk(0, q[0], k[0], 2, 0.5, 1)                                   # scale changed
+    assert slow == [1, 0, 0]
+    eng.tap_qk(1, torch.zeros(2, 16, 64, dtype=torch.float16).transpose(1, 2), k[2], 2, 0.35, 1)
+    assert slow == [1, 0, 0, 1]
+    eng.tap_qk(0, q[0], k[0], heads=2, scale=0.5, factor=1)
+    assert slow == [1, 0, 0, 1]                                            # cache hit on the Python side
+    with pytest.raises(IndexError):
+        eng.tap_qk(7, q[0], k[0], 2, 0.35, 1)
+    with pytest.raises(TypeError):
+        eng.tap_qk(0, q[0])
+    # the recorder keeps Q / K alive until the launch, then lets go
+    t = torch.zeros(2, 64, 16, dtype=torch.float16)
+    eng.tap_qk(0, t, k[0], 2, 0.5, 1)
+    del t
+    eng.flush()
+    assert eng.pending_taps == 0
+    eng.clear()
+    assert eng._fast.get_window() == 3 and eng.touched == []
+    eng.close()
+
+
+@pytest.mark.parametrize('recorder', ['c++', 'python'])
+def test_defer_byte_budget(fake_engine, monkeypatch, recorder):
+    """The recorded Q / K are kept alive until their launch: a byte budget forces the launch early."""
+    E, lib = fake_engine
+    if recorder == 'python':
+        monkeypatch.setenv('DAAM_NO_FASTPATH', '1')
+    q, k = torch.zeros(2, 64, 16, dtype=torch.float16), torch.zeros(2, 77, 16, dtype=torch.float16)
+    per_tap = (q.numel() + k.numel()) * 2
+    eng = E.HeatMapEngine(2, defer_steps=64, defer_bytes=5 * per_tap)
+    for step in range(7):
+        for layer in (1, 0):
+            eng.tap_qk(layer, q, k, 2, 0.35, 1)
+    # 2 taps per step; the budget (5 taps) is exceeded after 3 steps, and launches happen on step
+    # boundaries only: when steps 4 and 7 begin
+    assert lib.names().count('daam_tap_flush') == 2 and eng.pending_taps == 2
+    many = [c for c in lib.calls if c[0] == 'daam_tap_qk_enqueue_many']
+    assert [c[1][1] for c in many] == [6, 6]
+    eng.close()
 
 
 def test_engine_immediate_mode_and_dtype_rules(fake_engine):
