@@ -124,15 +124,20 @@ def measure_tap_kernel(eng, calls, defer, reps, fresh):
 
 
 def measure_finalize(eng, reps):
-    stream = torch.cuda.current_stream()
-    eng.global_heat_map()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(reps):
+    """HIP-event time of one compute_global_heat_map on the device: libdaam_hip brackets the table
+    upload + output zeroing + its finalize kernels with events on the launch stream."""
+    import ctypes
+    from daam_amd import _native as nat
+    nat.check(eng.lib.daam_profile_enable(eng.ctx, 1))
+    times = []
+    for r in range(reps + 2):
         eng.global_heat_map()
-    e1.record(stream)
-    e1.synchronize()
-    return e0.elapsed_time(e1) / reps
+        ms = ctypes.c_float()
+        nat.check(eng.lib.daam_profile_last_ms(eng.ctx, 1, ctypes.byref(ms)))
+        if r >= 2:
+            times.append(ms.value)
+    nat.check(eng.lib.daam_profile_enable(eng.ctx, 0))
+    return sum(times) / len(times)
 
 
 def cpu_baseline(kind, latent, denoise_steps, sample_steps=2):

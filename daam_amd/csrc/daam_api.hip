@@ -28,7 +28,7 @@ bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, i
 
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
-hipError_t launch_upload(void* dst, const void* src_host_mapped, size_t bytes, hipStream_t);
+hipError_t launch_upload(void* dst, const void* src_host_mapped, size_t bytes, void* zero, size_t zero_bytes, hipStream_t);
 hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
 hipError_t launch_finalize_up(const FinLaunch&, int side, int, int mfma_ok, hipStream_t, int*);
 bool finalize_up_supported(int side, int out_side);
@@ -119,8 +119,8 @@ struct Ring {
         return hipSuccess;
     }
     size_t cur_begin = 0, cur_end = 0;
-    hipError_t commit(size_t off, size_t bytes, hipStream_t s) {
-        return launch_upload(dev + off, host_dev + off, bytes, s);
+    hipError_t commit(size_t off, size_t bytes, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0) {
+        return launch_upload(dev + off, host_dev + off, bytes, zero, zero_bytes, s);
     }
     hipError_t release(hipStream_t s) {
         hipEvent_t ev;
@@ -167,6 +167,8 @@ struct DaamCtx {
     float* d_tab_w = nullptr;
     std::vector<int> tab_sides;
     std::vector<int> tab_fp16_exact;   // every (border-merged) tap weight is an fp16 number
+    void* d_up32_ops = nullptr;        // finalize_up32_mfma_kernel operands of the 32 -> 64 table (see build_up32_ops)
+    int up32_tab = -1;
     int no_mfma_finalize = 0;
     std::vector<Pending> pending;
     std::vector<int> pending_count;   // per layer: recorded steps
@@ -175,6 +177,7 @@ struct DaamCtx {
     int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
     int profile = 0;
     hipEvent_t prof_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+
     int force_generic = 0;
     int fast_exp = 0;
     int no_d64 = 0;
@@ -216,6 +219,34 @@ static int ensure_zeroed(Layer& l, hipStream_t s)
     return 0;
 }
 
+// MFMA operand pieces of finalize_up32_mfma_kernel (32 -> 64, fp16-exact banded tap matrix W[o][src]),
+// one 16-byte piece per (nt, lane, k): lane = (n = lane & 31, g = lane >> 5)
+//   k = 0, 1      : Wx, B of pass 1:  W[32nt + n][16ks + 8g + e],                      ks = k
+//   k = 2 + 2t+ks : Wy, A of pass 2:  W[32t + n][16ks + 8(i >> 2) + 4g + (i & 3)]     (contraction index
+//                   permuted to the C/D register order of pass 1, see the kernel)
+static std::vector<_Float16> build_up32_ops(const int16_t* idx, const float* w)
+{
+    auto W = [&](int o, int src) {
+        float v = 0.f;
+        for (int a = 0; a < 4; ++a)
+            if (idx[o * 4 + a] == src) v += w[o * 4 + a];
+        return (_Float16)v;
+    };
+    std::vector<_Float16> ops((size_t)2 * 64 * 6 * 8);
+    for (int nt = 0; nt < 2; ++nt)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int n = lane & 31, g = lane >> 5;
+            _Float16* dst = ops.data() + ((size_t)(nt * 64 + lane) * 6) * 8;
+            for (int ks = 0; ks < 2; ++ks)
+                for (int e = 0; e < 8; ++e) dst[ks * 8 + e] = W(32 * nt + n, 16 * ks + 8 * g + e);
+            for (int t = 0; t < 2; ++t)
+                for (int ks = 0; ks < 2; ++ks)
+                    for (int i = 0; i < 8; ++i)
+                        dst[(2 + 2 * t + ks) * 8 + i] = W(32 * t + n, 16 * ks + 8 * (i >> 2) + 4 * g + (i & 3));
+        }
+    return ops;
+}
+
 extern "C" {
 
 int daam_abi_version(void) { return DAAM_ABI_VERSION; }
@@ -251,6 +282,7 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->no_mfma_finalize = nm && nm[0] == '1';
     const char* n16 = getenv("DAAM_NO_D64");            // debugging: 32x32-tile kernel also for head_dim 64
     c->no_d64 = n16 && n16[0] == '1';
+
     // softmax flavour of the MFMA tap: fast (default; exponent by one mixed-precision FMA, ~1e-6 relative,
     // same deviation class as the f32 summation order of q.k -- DESIGN.md section 3.1) or compensated
     // (DAAM_STRICT_EXP=1 / DAAM_FAST_EXP=0: ~1 ulp f32 like the reference's expf)
@@ -271,6 +303,7 @@ int daam_ctx_destroy(DaamCtx* c)
     for (auto& pair : c->prof_ev)
         for (auto& ev : pair)
             if (ev) (void)hipEventDestroy(ev);
+    if (c->d_up32_ops) (void)hipFree(c->d_up32_ops);
     if (c->d_tab_idx) (void)hipFree(c->d_tab_idx);
     if (c->d_tab_w) (void)hipFree(c->d_tab_w);
     delete c;
@@ -322,6 +355,12 @@ int daam_layer_configure(DaamCtx* c, int layer, int heads, int side, int factor,
                     exact = ((float)(_Float16)merged == merged) && ((float)(_Float16)w[j * 4 + a] == w[j * 4 + a]);
                 }
             c->tab_fp16_exact.push_back(exact);
+            if (exact && side == 32 && c->out_side == 64 && !c->d_up32_ops) {
+                std::vector<_Float16> ops = build_up32_ops(idx.data(), w.data());
+                HIP_TRY(hipMalloc(&c->d_up32_ops, ops.size() * sizeof(_Float16)));
+                HIP_TRY(hipMemcpy(c->d_up32_ops, ops.data(), ops.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+                c->up32_tab = tab;
+            }
         }
         l.tab = tab;
     }
@@ -683,7 +722,9 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     if (max_side > 128) return fail(DAAM_E_UNSUPPORTED, "map side %d > 128 not supported by finalize", max_side);
     hipStream_t s = (hipStream_t)stream;
     const size_t plane = (size_t)c->out_side * c->out_side;
-    HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * c->tokens * plane, s));
+    const size_t out_bytes = sizeof(float) * c->tokens * plane;
+    const bool zero_in_upload = out_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    if (!zero_in_upload) HIP_TRY(hipMemsetAsync(out, 0, out_bytes, s));
     size_t off = 0;
     const size_t bytes = (size_t)total * sizeof(FinKey);
     HIP_TRY(c->ring.alloc(bytes, &off));
@@ -691,16 +732,17 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         FinKey* dst = reinterpret_cast<FinKey*>(c->ring.host + off);
         for (auto& v : keys) { memcpy(dst, v.data(), v.size() * sizeof(FinKey)); dst += v.size(); }
     }
-    HIP_TRY(c->ring.commit(off, bytes, s));
+    if (c->profile) (void)hipEventRecord(c->prof_ev[1][0], s);    // timed: table upload + zeroing + the class kernels
+    HIP_TRY(c->ring.commit(off, bytes, s, zero_in_upload ? out : nullptr, zero_in_upload ? out_bytes : 0));
     const FinKey* dev = reinterpret_cast<const FinKey*>(c->ring.dev + off);
     c->last_block[1] = 256;
     c->last_grid[1] = 0;
     c->last_lds[1] = 0;
     static const int env_chunks = getenv("DAAM_FIN_CHUNKS") ? atoi(getenv("DAAM_FIN_CHUNKS")) : 0;
-    if (c->profile) (void)hipEventRecord(c->prof_ev[1][0], s);
     for (int cls = 0; cls < 4; ++cls) {
         const int n = (int)keys[cls].size();
         if (n == 0) { continue; }
+
         FinLaunch L;
         L.keys = dev;
         dev += n;
@@ -712,6 +754,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         L.out_side = c->out_side;
         L.inv_n = 1.0f / (float)total;
         L.max_side = max_side;
+        L.mfma_ops = (cls == 1 && keys[cls][0].tab == c->up32_tab) ? c->d_up32_ops : nullptr;
         int grid = 0, lds = 0;
         hipError_t e;
         if (cls == 0) {
@@ -725,7 +768,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             // (two full rounds at 2 workgroups per CU) measured best: fewer leaves a ragged tail,
             // more pays the per-workgroup reduction + atomics too often.
             const int want = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
-            L.n_chunks = std::max(std::max(1, std::min((n + 3) / 4, want)), (n + 255) / 256);
+            L.n_chunks = std::max(std::max(1, std::min((n + 3) / 4, want)), (n + 127) / 128);   // <= 64 keys per wave (2 or 4 key lanes per workgroup)
             e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, c->tab_fp16_exact[keys[cls][0].tab] && !c->no_mfma_finalize, s, &grid);
         }
         if (e != hipSuccess) return fail((int)e, "finalize launch (class %d): %s", cls, hipGetErrorString(e));

@@ -18,6 +18,7 @@ namespace daam {
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 template <typename T> struct Plane;
 template <> struct Plane<_Float16> {
@@ -234,88 +235,70 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
                     [&](int i) { return i * O + lane; }, L.out + (size_t)tok * O * O, L.inv_n);
 }
 
-// ---------------------------------------------------------------------------------------
-// x2 (32 -> 64) for fp16 planes, no LDS on the data path.
-//   x pass = T[y][ox] = sum_x A[y][x] Wx[ox][x] on the matrix cores (v_mfma_f32_32x32x16_f16): the
-//   A operand is the plane itself, 16 bytes per lane straight from HBM (lane = source row y, half
-//   g -> columns 16ks+8g..+7); the B operand is the banded 32x64 tap matrix built once per wave from
-//   the host tables (every tap weight of the x2 bicubic, and every border-merged sum of them, is
-//   exactly representable in fp16 -- checked on the host, else the LDS kernel is used).  Products of
-//   two fp16 values are exact in f32 and at most 4 are non-zero per output, so T equals the
-//   reference's f32 x interpolation up to the summation order.
-//   The C/D layout leaves lane (j, g) with column ox = j (+32 for the second tile) and rows
-//   {8b+4g+r}: 8 v_permlane32_swap per tile regroup that into rows [16g, 16g+16) of the column,
-//   2 more swaps fetch the two halo rows on each side from the partner lane (border lanes clamp),
-//   and the y pass + clamp + accumulate run on registers with compile-time row taps; lane half g
-//   owns output rows [32g, 32g+32) of its column.
-// ---------------------------------------------------------------------------------------
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ void swap32(float& x, float& y) {
-    // x <- {x.lo, y.lo}, y <- {x.hi, y.hi}   (lo / hi = lanes 0-31 / 32-63)
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    x = __uint_as_float(r[0]);
-    y = __uint_as_float(r[1]);
+// ---------------------------------------------------------------------------------------
+// x2 (32 -> 64) for fp16 planes with BOTH bicubic passes on the matrix cores.
+//   pass 1 (x):  T = P Wx^T on v_mfma_f32_32x32x16_f16.  The A operand is the plane itself, 16 bytes per
+//   lane straight from HBM (lane = source row y, half g -> columns 16ks + 8g .. +7); the B operand is the
+//   banded 32x64 tap matrix (every tap weight of the x2 bicubic, and every border-merged sum of them, is
+//   exactly representable in fp16 -- checked on the host, else the LDS kernel above is used).  Products
+//   of two fp16 values are exact in f32 and at most 4 are non-zero per output, so T equals the
+//   reference's f32 x interpolation up to the summation order.  C/D layout: lane (ox, g) holds rows
+//   y = 8b + 4g + r of T[y][ox] in register 4b + r.
+//   pass 2 (y):  out = Wy T  with T as the B operand.  The contraction index of an MFMA can be
+//   permuted freely as long as A and B agree, so the C/D registers of pass 1 ARE a valid B operand:
+//   k-step ks2, slot (g, i)  <->  y = 16 ks2 + 8 (i >> 2) + 4g + (i & 3) = the row held in register
+//   8 ks2 + i.  The constant Wy pieces are built once per wave with the same permutation: no lane
+//   exchange, no LDS.  T is fed as an fp16 pair hi + lo (hi = fp16(T), lo = fp16(T - hi)): 22
+//   significant bits, |error| <= 2^-22 |T| -- below the f32 rounding noise of the four-tap sums it
+//   feeds, far inside the tolerance of the bicubic parity tests; Wy is exact in fp16 (host check).
+//   VALU work per plane: the hi/lo split + clamp / accumulate of the outputs (~165 instructions per 64x64
+//   plane, against ~300 for a register y pass with lane exchanges); the MFMA pipe does 4 + 16 instructions.
+//   Measured (SDXL-1024, 1000 planes x 77 tokens): ~68 us either way -- the kernel is bound by its
+//   epilogue (4.1 M float atomics, ~24 us) and by HBM latency at 2 KB per plane, not by the loop.
+//   C/D of pass 2: lane (ox, g) owns out[32mt + 8b + 4g + r][32nt + ox].
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ half2v fin_cvt_pk(float a, float b) {
+    half2v r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
-__global__ __launch_bounds__(256) void finalize_up32_mfma_kernel(const FinLaunch L)
+__global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLaunch L)
 {
+    // wave = (nt, kq): output columns [32nt, 32nt+32) of every second key of the workgroup's chunk.  Half the
+    // output per wave keeps the kernel under 128 VGPRs (4 waves per SIMD: the MFMA chain of one wave
+    // runs under the VALU work of the others); the plane is fetched by both nt waves (second one hits L2).
     constexpr int S = 32, O = 64;
-    constexpr int kDepth = 4, kMaxKeysPerWave = 64;
-    __shared__ const void* kbase[4][kMaxKeysPerWave];
-    __shared__ __align__(16) float red[2 * O * O];
+    constexpr int kDepth = 2, kMaxKeysPerWave = 64;
+    __shared__ const void* kbase[2][kMaxKeysPerWave];
+    __shared__ __align__(16) float red[2][32 * 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, g = lane >> 5;
+    const int nt = wave & 1, kq = wave >> 1;
     const int tok = blockIdx.x;
 
-    const int tab = as_global<FinKey>(L.keys)[0].tab;
-    const int16_t* tix = L.tab_idx + (size_t)tab * O * 4;
-    const float* tw = L.tab_w + (size_t)tab * O * 4;
+    // operand pieces of the banded tap matrix, built on the host (build_up32_ops in daam_api.hip):
+    //   wx[ks][e]    = W[32nt + n][16ks + 8g + e]                              (B of pass 1)
+    //   wy[t][ks][i] = W[32t + n][16ks + 8(i >> 2) + 4g + (i & 3)]             (A of pass 2, permuted k)
+    const DAAM_GLOBAL half8* ops = as_global<half8>(L.mfma_ops) + (size_t)(nt * 64 + lane) * 6;
+    half8 wx[2], wy[2][2];
+    wx[0] = ops[0]; wx[1] = ops[1];
+    wy[0][0] = ops[2]; wy[0][1] = ops[3]; wy[1][0] = ops[4]; wy[1][1] = ops[5];
 
-    // B operand: wb[nt][ks][e] = Wx[ox = 32nt + n][x = 16ks + 8g + e]
-    half8 wb[2][2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int ox = 32 * nt + n;
-        int ix[4];
-        float wv[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { ix[a] = tix[ox * 4 + a]; wv[a] = tw[ox * 4 + a]; }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int x = 16 * ks + 8 * g + e;
-                float w = 0.f;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) w += (ix[a] == x) ? wv[a] : 0.f;
-                wb[nt][ks][e] = (_Float16)w;
-            }
-    }
-    // y weights: output row parity 0 (t = 0.75) and 1 (t = 0.25)
-    float wy[2][4];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) wy[p][a] = tw[p * 4 + a];
+    floatx16 acc[2] = {floatx16{0}, floatx16{0}};             // [mt]
 
-    // acc[nt][o'] = output row 32g + o' of column 32nt + n
-    float acc[2][32];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int i = 0; i < 32; ++i) acc[nt][i] = 0.f;
-
-    const int stride = gridDim.y * 4;
-    const int first = blockIdx.y * 4 + wave;
+    const int stride = gridDim.y * 2;
+    const int first = blockIdx.y * 2 + kq;
     const int nk = first < L.n_keys ? min((L.n_keys - first + stride - 1) / stride, kMaxKeysPerWave) : 0;
-    if (lane < nk) kbase[wave][lane] = as_global<FinKey>(L.keys)[first + lane * stride].base;
-    __builtin_amdgcn_wave_barrier();
+    if (nt == 0 && lane < nk) kbase[kq][lane] = as_global<FinKey>(L.keys)[first + lane * stride].base;
+    __syncthreads();
 
     half8 pre[kDepth][2];
     auto fetch = [&](int i, half8 (&dst)[2]) {
-        const _Float16* src = reinterpret_cast<const _Float16*>(kbase[wave][i]) + (size_t)tok * S * S + n * S + 8 * g;
+        const _Float16* src = reinterpret_cast<const _Float16*>(kbase[kq][i]) + (size_t)tok * S * S + n * S + 8 * g;
         dst[0] = *as_global<half8>(src);
         dst[1] = *as_global<half8>(src + 16);
     };
@@ -328,80 +311,49 @@ __global__ __launch_bounds__(256) void finalize_up32_mfma_kernel(const FinLaunch
       for (int d = 0; d < kDepth; ++d) {
         const int ki = i0 + d;
         if (ki >= nk) break;
-        floatx16 c[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            c[nt] = floatx16{0};
-            c[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][0], wb[nt][0], c[nt], 0, 0, 0);
-            c[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][1], wb[nt][1], c[nt], 0, 0, 0);
-        }
+        floatx16 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][0], wx[0], floatx16{0}, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][1], wx[1], c, 0, 0, 0);
         if (ki + kDepth < nk) fetch(ki + kDepth, pre[d]);
+        half8 bhi[2], blo[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            // e[q + 2] = source row 16g + q of this lane's column, q = -2 .. 17
-            float e[20];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = c[nt][4 * b + r], y = c[nt][4 * (b + 2) + r];
-                    swap32(x, y);
-                    e[2 + 8 * b + r] = x;                       // row 16g + 8b + r
-                    e[2 + 8 * b + 4 + r] = y;                   // row 16g + 8b + 4 + r
-                }
-            {
-                float xa = e[2 + 0], ya = e[2 + 14], xb = e[2 + 1], yb = e[2 + 15];
-                swap32(xa, ya);                                 // upper lanes: xa = partner's q=14; lower: ya = partner's q=0
-                swap32(xb, yb);                                 // upper lanes: xb = partner's q=15; lower: yb = partner's q=1
-                e[0] = g ? xa : e[2];                           // rows -2, -1 clamp to row 0 for the lower half
-                e[1] = g ? xb : e[2];
-                e[18] = g ? e[17] : ya;                         // rows 32, 33 clamp to row 31 for the upper half
-                e[19] = g ? e[17] : yb;
+            for (int i = 0; i < 8; i += 2) {
+                const float t0 = c[8 * ks + i], t1 = c[8 * ks + i + 1];
+                const half2v hi = fin_cvt_pk(t0, t1);
+                const half2v lo = fin_cvt_pk(t0 - (float)hi[0], t1 - (float)hi[1]);
+                bhi[ks][i] = hi[0]; bhi[ks][i + 1] = hi[1];
+                blo[ks][i] = lo[0]; blo[ks][i + 1] = lo[1];
             }
-            // output row o' (global 32g + o'): taps local q = f'-1 .. f'+2, f' = floor(o'/2 - 1/4)
-            {
-                // singles o' = 0 (f' = -1) and o' = 31 (f' = 15)
-                float v0 = e[0] * wy[0][0];
-                v0 = __builtin_fmaf(e[1], wy[0][1], v0);
-                v0 = __builtin_fmaf(e[2], wy[0][2], v0);
-                v0 = __builtin_fmaf(e[3], wy[0][3], v0);
-                acc[nt][0] += fmaxf(v0, 0.f);
-                float v1 = e[16] * wy[1][0];
-                v1 = __builtin_fmaf(e[17], wy[1][1], v1);
-                v1 = __builtin_fmaf(e[18], wy[1][2], v1);
-                v1 = __builtin_fmaf(e[19], wy[1][3], v1);
-                acc[nt][31] += fmaxf(v1, 0.f);
-            }
-            // pairs (o', o'+1), o' odd: both have f' = (o'-1)/2, taps q = f'-1 .. f'+2
-            constexpr int YB = 5;
+        floatx16 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[0][0], bhi[0], floatx16{0}, 0, 0, 0);
+        floatx16 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[1][0], bhi[0], floatx16{0}, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[0][1], bhi[1], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[1][1], bhi[1], o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[0][0], blo[0], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[1][0], blo[0], o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[0][1], blo[1], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[1][1], blo[1], o1, 0, 0, 0);
 #pragma unroll
-            for (int p0 = 0; p0 < 15; p0 += YB) {
-                float2v v[YB];
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int j = 0; j < YB; ++j) {
-                        const int op = 1 + 2 * (p0 + j);                  // odd o'
-                        const int f = (op - 1) / 2;
-                        const float hv = e[2 + f - 1 + a];
-                        const float2v w = {wy[1][a], wy[0][a]};          // (odd row, even row)
-                        v[j] = a == 0 ? float2v{hv, hv} * w : __builtin_elementwise_fma(float2v{hv, hv}, w, v[j]);
-                    }
-#pragma unroll
-                for (int j = 0; j < YB; ++j) {
-                    const int op = 1 + 2 * (p0 + j);
-                    acc[nt][op] += fmaxf(v[j][0], 0.f);
-                    acc[nt][op + 1] += fmaxf(v[j][1], 0.f);
-                }
-            }
+        for (int v = 0; v < 16; ++v) {
+            acc[0][v] += fmaxf(o0[v], 0.f);
+            acc[1][v] += fmaxf(o1[v], 0.f);
         }
       }
     }
-    // element i = (tile i / 32, local row i % 32)  ->  out[32g + i % 32][32 (i / 32) + n]
-    wg_reduce_flush(red, wave, [&](int i) { return acc[i >> 5][i & 31]; },
-                    [&](int i, float v) { acc[i >> 5][i & 31] += v; },
-                    [&](int i) { return (32 * g + (i & 31)) * O + 32 * (i >> 5) + n; },
-                    L.out + (size_t)tok * O * O, L.inv_n);
+    // the two key halves of an nt tile meet in LDS; the kq = 0 wave adds the sum into the output
+    if (kq == 1) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) red[nt][i * 64 + lane] = acc[i >> 4][i & 15];
+    }
+    __syncthreads();
+    if (kq == 0) {
+        float* out = L.out + (size_t)tok * O * O + 32 * nt + n;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int row = 32 * (i >> 4) + 8 * ((i & 15) >> 2) + 4 * g + (i & 3);
+            atomicAdd(out + row * O, (acc[i >> 4][i & 15] + red[nt][i * 64 + lane]) * L.inv_n);
+        }
+    }
 }
 
 // side == out_side: out[t][i] += sum over this chunk's keys of max(plane[t][i], 0) / N.
@@ -474,7 +426,7 @@ hipError_t launch_finalize_up(const FinLaunch& L, int side, int acc_dtype, int m
 {
     dim3 grid(L.tokens, L.n_chunks);
     *grid_out = grid.x * grid.y;
-    if (side == 32 && acc_dtype == 0 && mfma_ok) {
+    if (side == 32 && acc_dtype == 0 && mfma_ok && L.mfma_ops) {
         hipLaunchKernelGGL(finalize_up32_mfma_kernel, grid, dim3(256), 0, stream, L);
     } else if (side == 32) {
         if (acc_dtype == 0) hipLaunchKernelGGL((finalize_up_kernel<_Float16, 32>), grid, dim3(256), 0, stream, L);

@@ -357,17 +357,22 @@ __global__ __launch_bounds__(256) void word_post_kernel(float* out, int n, const
 
 // per-launch device tables: pinned host (device-mapped) -> device twin, in stream order on the
 // compute queue (16 bytes per thread; tables are a few tens of KB)
-__global__ __launch_bounds__(256) void upload_kernel(float4* dst, const float4* src, int n16)
+__global__ __launch_bounds__(256) void upload_kernel(float4* dst, const float4* src, int n16, float4* zero, int z16)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n16) dst[i] = src[i];
+    else if (i - n16 < z16) zero[i - n16] = float4{0.f, 0.f, 0.f, 0.f};
 }
 
-hipError_t launch_upload(void* dst, const void* src_host_mapped, size_t bytes, hipStream_t stream)
+// `zero` / `zero_bytes` (16-byte multiple, may be 0): a buffer cleared by the same launch (the finalize
+// output, which is accumulated with atomics) -- saves a separate memset on the critical path
+hipError_t launch_upload(void* dst, const void* src_host_mapped, size_t bytes, void* zero, size_t zero_bytes,
+                         hipStream_t stream)
 {
     const int n16 = (int)((bytes + 15) / 16);                 // ring slots are 256-byte aligned and padded
-    hipLaunchKernelGGL(upload_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream, reinterpret_cast<float4*>(dst),
-                       reinterpret_cast<const float4*>(src_host_mapped), n16);
+    const int z16 = (int)(zero_bytes / 16);
+    hipLaunchKernelGGL(upload_kernel, dim3((n16 + z16 + 255) / 256), dim3(256), 0, stream, reinterpret_cast<float4*>(dst),
+                       reinterpret_cast<const float4*>(src_host_mapped), n16, reinterpret_cast<float4*>(zero), z16);
     return hipGetLastError();
 }
 

@@ -85,6 +85,7 @@ struct FinLaunch {
     int32_t out_side;
     float inv_n;
     int32_t max_side;       // largest non-identity side among the keys (LDS carve-up)
+    const void* mfma_ops;   // x2 MFMA finalize: [2 nt][64 lanes][6] 16-byte operand pieces (host-built), or NULL
 };
 
 }  // namespace daam

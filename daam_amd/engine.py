@@ -54,6 +54,7 @@ class HeatMapEngine:
         self._cnt: List[int] = [0] * self.n_layers      # recorded steps per layer
         self._qk_cache: List[Optional[tuple]] = [None] * self.n_layers
         self._touched_flag: List[bool] = [False] * self.n_layers
+        self._mask_cache: Dict[tuple, tuple] = {}        # finalize key masks per selection
         # deferred mode: the per-call bookkeeping runs in the C++ recorder (csrc/daam_fastpath.cpp) when
         # that extension is built; the Python implementation below is the same logic and stays the
         # slow path (first call of a layer, shape changes) and the fallback.  Both only record host-side
@@ -128,6 +129,7 @@ class HeatMapEngine:
         nat.check(self.lib.daam_layer_configure(self.ctx, layer, heads, side, factor, buf.data_ptr()))
         self.acc[layer] = buf
         self.layer_info[layer] = (factor, heads, side)
+        self._mask_cache.clear()
 
     def _touch(self, layer: int) -> None:
         if not self._touched_flag[layer]:
@@ -337,20 +339,29 @@ class HeatMapEngine:
         if self.ctx is None or not self.touched:
             raise LookupError('no heat maps')
         self.flush()
-        total = ctypes.c_int()
-        nat.check(self.lib.daam_key_offset(self.ctx, 0, None, ctypes.byref(total)))
-        mask = (ctypes.c_uint8 * total.value)()
-        n = 0
-        for layer in self.touched:
-            factor, heads, _ = self.layer_info[layer]
-            if factor not in fset or (layer_idx is not None and layer_idx != layer):
-                continue
-            off = ctypes.c_int()
-            nat.check(self.lib.daam_key_offset(self.ctx, layer, ctypes.byref(off), None))
-            for h in range(heads):
-                if head_idx is None or head_idx == h:
-                    mask[off.value + h] = 1
-                    n += 1
+        # key mask in the library's key order (configured layers by index, heads inside); cached per
+        # selection -- building it costs more host time than the finalize kernels take on the device
+        sel = (tuple(sorted(fset)), head_idx, layer_idx, tuple(self.touched), len(self.layer_info))
+        cached = self._mask_cache.get(sel)
+        if cached is None:
+            total = ctypes.c_int()
+            nat.check(self.lib.daam_key_offset(self.ctx, 0, None, ctypes.byref(total)))
+            mask = (ctypes.c_uint8 * total.value)()
+            n = 0
+            for layer in self.touched:
+                factor, heads, _ = self.layer_info[layer]
+                if factor not in fset or (layer_idx is not None and layer_idx != layer):
+                    continue
+                off = ctypes.c_int()
+                nat.check(self.lib.daam_key_offset(self.ctx, layer, ctypes.byref(off), None))
+                for h in range(heads):
+                    if head_idx is None or head_idx == h:
+                        mask[off.value + h] = 1
+                        n += 1
+            if len(self._mask_cache) > 64:
+                self._mask_cache.clear()
+            cached = self._mask_cache[sel] = (mask, n)
+        mask, n = cached
         if n == 0:
             raise LookupError('no heat maps')
         out = torch.empty(self.tokens, self.out_side, self.out_side, dtype=torch.float32, device=self.device)

@@ -113,16 +113,18 @@ def test_generic_and_mfma_agree(monkeypatch):
     assert (diff > 0).mean() < 0.02
 
 
-def test_deferred_equals_immediate_bits():
-    """Deferring steps changes the launch structure, not one bit of the result."""
+@pytest.mark.parametrize('steps,d', [(7, 64), (70, 64), (70, 40)])
+def test_deferred_equals_immediate_bits(steps, d):
+    """Deferring steps changes the launch structure, not one bit of the result -- also when a whole
+    50-step generation (or more: 70 steps = a full 64-step launch + 6) runs as one launch, with the fp16
+    running sums carried in registers across the steps."""
     rng = np.random.default_rng(11)
-    steps = 7
-    data = [_qk(rng, 2, 2, 256, 64, np.float16) for _ in range(steps)]
+    data = [_qk(rng, 2, 2, 256, d, np.float16) for _ in range(steps)]
     res = []
-    for defer in (0, 1, 3, 50):
+    for defer in (0, 1, 3, 64):
         eng = _engine(defer_steps=defer)
         for q, k in data:
-            eng.tap_qk(1, torch.from_numpy(q).to(DEV), torch.from_numpy(k).to(DEV), 2, 0.125, factor=4)
+            eng.tap_qk(1, torch.from_numpy(q).to(DEV), torch.from_numpy(k).to(DEV), 2, d ** -0.5, factor=4)
         res.append(torch.stack([v for _, v in eng.items()]).cpu())
         eng.close()
     for r in res[1:]:
