@@ -15,6 +15,16 @@
 
 namespace daam {
 
+// debug aid (tools/fin_timing.py; build with -DDAAM_FIN_TIMING): per-workgroup phase timestamps of the x2 MFMA kernel
+#ifdef DAAM_FIN_TIMING
+__device__ unsigned long long daam_fin_dbg[1024][4];
+#define DAAM_FT(i) do { if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1024) \
+    daam_fin_dbg[blockIdx.y * gridDim.x + blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DAAM_FT(i) do {} while (0)
+#endif
+
+
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -279,6 +289,7 @@ __global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLau
     const int n = lane & 31, g = lane >> 5;
     const int nt = wave & 1, kq = wave >> 1;
     const int tok = blockIdx.x;
+    DAAM_FT(0);
 
     // operand pieces of the banded tap matrix, built on the host (build_up32_ops in daam_api.hip):
     //   wx[ks][e]    = W[32nt + n][16ks + 8g + e]                              (B of pass 1)
@@ -296,6 +307,7 @@ __global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLau
     if (nt == 0 && lane < nk) kbase[kq][lane] = as_global<FinKey>(L.keys)[first + lane * stride].base;
     __syncthreads();
 
+    DAAM_FT(1);
     half8 pre[kDepth][2];
     auto fetch = [&](int i, half8 (&dst)[2]) {
         const _Float16* src = reinterpret_cast<const _Float16*>(kbase[kq][i]) + (size_t)tok * S * S + n * S + 8 * g;
@@ -340,6 +352,7 @@ __global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLau
         }
       }
     }
+    DAAM_FT(2);
     // the two key halves of an nt tile meet in LDS; the kq = 0 wave adds the sum into the output
     if (kq == 1) {
 #pragma unroll
@@ -354,7 +367,16 @@ __global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLau
             atomicAdd(out + row * O, (acc[i >> 4][i & 15] + red[nt][i * 64 + lane]) * L.inv_n);
         }
     }
+    DAAM_FT(3);
 }
+
+#ifdef DAAM_FIN_TIMING
+}  // namespace daam
+extern "C" int daam_debug_dump_fin(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(daam::daam_fin_dbg), sizeof(daam::daam_fin_dbg));
+}
+namespace daam {
+#endif
 
 // side == out_side: out[t][i] += sum over this chunk's keys of max(plane[t][i], 0) / N.
 // A wave owns 64 consecutive 16-byte pieces of one token plane; kBatch keys are in flight per
