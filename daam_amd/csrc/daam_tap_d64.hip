@@ -69,13 +69,20 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
         // (fp16(c) * 2^k == fp16(c * 2^k) unless the result is an fp16 subnormal, |logit| < 6.1e-5,
         // where the two differ by < 6e-8 absolute): the logits stay unscaled in fp16 and the scale
         // is folded into the exponent FMA.
-        const bool pow2 = (__float_as_uint(lay.scale) & 0x007fffffu) == 0;
-        const float pre = pow2 ? 1.0f : lay.scale;
+        const bool pow2 = (__float_as_uint(lay.scale) & 0x007fffffu) == 0;      // wave-uniform
         half2v xh[kSlots16 / 2];
+        if (pow2) {
 #pragma unroll
-        for (int mt = 0; mt < 5; ++mt) {
-            xh[2 * mt] = cvt_pk_rne(float2v{c[mt][0], c[mt][1]} * pre);
-            xh[2 * mt + 1] = cvt_pk_rne(float2v{c[mt][2], c[mt][3]} * pre);
+            for (int mt = 0; mt < 5; ++mt) {
+                xh[2 * mt] = cvt_pk_rne(float2v{c[mt][0], c[mt][1]});
+                xh[2 * mt + 1] = cvt_pk_rne(float2v{c[mt][2], c[mt][3]});
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                xh[2 * mt] = cvt_pk_rne(float2v{c[mt][0], c[mt][1]} * lay.scale);
+                xh[2 * mt + 1] = cvt_pk_rne(float2v{c[mt][2], c[mt][3]} * lay.scale);
+            }
         }
         if (h == 3) {                                                   // tokens 77, 78, 79
             const _Float16 ninf = -(_Float16)__builtin_inff();
