@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32,
 LIB_NAME = 'libdaam_hip.so'
 LIB_PATH = os.environ.get('DAAM_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-DAAM_F16, DAAM_F32 = 0, 1
+DAAM_F16, DAAM_F32, DAAM_BF16 = 0, 1, 2
 E_INVALID, E_STATE, E_NOMAPS, E_UNSUPPORTED = -1, -2, -3, -4
 
 # every symbol include/daam_hip.h declares (tests check the library exports exactly these)
@@ -90,5 +90,5 @@ def check(rc: int) -> None:
         raise DaamError(rc, msg.decode() if msg else '')
 
 
-__all__ = ['load', 'check', 'DaamError', 'QKDesc', 'DAAM_F16', 'DAAM_F32', 'EXPORTS', 'LIB_PATH',
+__all__ = ['load', 'check', 'DaamError', 'QKDesc', 'DAAM_F16', 'DAAM_F32', 'DAAM_BF16', 'EXPORTS', 'LIB_PATH',
            'byref', 'c_void_p', 'c_int', 'c_uint8', 'c_int32', 'c_size_t', 'E_NOMAPS']

@@ -183,7 +183,10 @@ struct DaamCtx {
     int no_d64 = 0;
 };
 
-static size_t acc_elem(int dtype) { return dtype == DAAM_F16 ? 2 : 4; }
+static size_t acc_elem(int dtype) { return dtype == DAAM_F32 ? 4 : 2; }
+
+// which running-sum dtypes a pipeline dtype may feed: its own (the reference's behaviour) or f32
+static bool dtypes_compatible(int in_dtype, int acc_dtype) { return acc_dtype == DAAM_F32 || acc_dtype == in_dtype; }
 
 // torch upsample_bicubic2d, align_corners=False, antialias=False:
 // scale = in / out in f32; src = scale * (dst + 0.5) - 0.5 (NOT clamped for cubic);
@@ -259,7 +262,7 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     if (max_layers <= 0 || max_layers > 4096) return fail(DAAM_E_INVALID, "max_layers %d out of range", max_layers);
     if (tokens <= 0 || tokens > kMaxTokens) return fail(DAAM_E_INVALID, "tokens %d not in 1..%d", tokens, kMaxTokens);
     if (out_side <= 0 || out_side > 128) return fail(DAAM_E_INVALID, "out_side %d not in 1..128", out_side);
-    if (acc_dtype != DAAM_F16 && acc_dtype != DAAM_F32) return fail(DAAM_E_INVALID, "acc_dtype %d", acc_dtype);
+    if (acc_dtype != DAAM_F16 && acc_dtype != DAAM_F32 && acc_dtype != DAAM_BF16) return fail(DAAM_E_INVALID, "acc_dtype %d", acc_dtype);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail((int)hipErrorNoDevice, "no HIP device");
@@ -402,9 +405,9 @@ static int check_qk(DaamCtx* c, int layer, const void* q, const void* k, const D
     if (layer < 0 || layer >= c->max_layers || !c->layers[layer].configured)
         return fail(DAAM_E_STATE, "layer %d not configured", layer);
     const Layer& l = c->layers[layer];
-    if (d->in_dtype != DAAM_F16 && d->in_dtype != DAAM_F32) return fail(DAAM_E_INVALID, "in_dtype %d", d->in_dtype);
-    if (d->in_dtype == DAAM_F32 && c->acc_dtype == DAAM_F16)
-        return fail(DAAM_E_INVALID, "fp32 activations need fp32 running sums");
+    if (d->in_dtype != DAAM_F16 && d->in_dtype != DAAM_F32 && d->in_dtype != DAAM_BF16) return fail(DAAM_E_INVALID, "in_dtype %d", d->in_dtype);
+    if (!dtypes_compatible(d->in_dtype, c->acc_dtype))
+        return fail(DAAM_E_INVALID, "activations of dtype %d cannot feed running sums of dtype %d (own dtype or f32)", d->in_dtype, c->acc_dtype);
     if (d->tokens != c->tokens) return fail(DAAM_E_INVALID, "tokens %d != context size %d (reference gate, trace.py:289)", d->tokens, c->tokens);
     if (d->batch <= 0 || d->heads <= 0 || d->head_dim <= 0 || d->head_dim > 1024)
         return fail(DAAM_E_INVALID, "batch %d heads %d head_dim %d", d->batch, d->heads, d->head_dim);
@@ -647,8 +650,9 @@ int daam_tap_probs(DaamCtx* c, int layer, const void* probs, int in_dtype, int b
         return fail(DAAM_E_STATE, "layer %d not configured", layer);
     if (!c->pending.empty()) return fail(DAAM_E_STATE, "probs tap with deferred taps pending: flush first");
     const Layer& l = c->layers[layer];
-    if (in_dtype != DAAM_F16 && in_dtype != DAAM_F32) return fail(DAAM_E_INVALID, "in_dtype %d", in_dtype);
-    if (in_dtype == DAAM_F32 && c->acc_dtype == DAAM_F16) return fail(DAAM_E_INVALID, "fp32 probabilities need fp32 running sums");
+    if (in_dtype != DAAM_F16 && in_dtype != DAAM_F32 && in_dtype != DAAM_BF16) return fail(DAAM_E_INVALID, "in_dtype %d", in_dtype);
+    if (!dtypes_compatible(in_dtype, c->acc_dtype))
+        return fail(DAAM_E_INVALID, "probabilities of dtype %d cannot feed running sums of dtype %d (own dtype or f32)", in_dtype, c->acc_dtype);
     if (tokens != c->tokens) return fail(DAAM_E_INVALID, "tokens %d != context size %d", tokens, c->tokens);
     if (batch_heads - batch_heads / 2 != l.heads || hw != l.hw)
         return fail(DAAM_E_INVALID, "layer %d is [%d heads, %d positions], call has [%d kept, %d]", layer, l.heads, l.hw,
@@ -709,7 +713,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             k.side = l.side;
             k.tab = l.tab;
             int cls = 3;
-            if (!c->force_generic) {
+            if (!c->force_generic && c->acc_dtype != DAAM_BF16) {     // bf16 planes: any-shape kernel only
                 if (l.tab < 0 && (l.hw % 8) == 0) cls = 0;
                 else if (l.tab >= 0 && finalize_up_supported(l.side, c->out_side)) cls = l.side == 32 ? 1 : 2;
             }

@@ -17,10 +17,12 @@ namespace daam {
 template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<__half>(const __half* p) { return __half2float(*p); }
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
 
 template <typename T> __device__ __forceinline__ float round_to(float x);
 template <> __device__ __forceinline__ float round_to<__half>(float x) { return __half2float(__float2half_rn(x)); }
 template <> __device__ __forceinline__ float round_to<float>(float x) { return x; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float x) { return bf16_to_f32(f32_to_bf16(x)); }
 
 // acc = acc + x in the accumulator dtype.  For fp16 the f32 add of two fp16 values followed by
 // one RNE rounding is the correctly rounded fp16 add (24 >= 2*11+2 bits), i.e. exactly what
@@ -28,6 +30,8 @@ template <> __device__ __forceinline__ float round_to<float>(float x) { return x
 template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<__half>(__half* p, float v) { *p = __float2half_rn(v); }
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+// bf16: f32 add of two bf16 values + one RNE rounding = the correctly rounded bf16 add (24 >= 2*8+2 bits)
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 
 // XCD-aware block remap: hardware places block b on XCD b % 8; give each XCD a contiguous
 // range of logical tiles so the tiles of one (layer, head) - which share K - share an L2.
@@ -400,7 +404,10 @@ hipError_t launch_tap_generic(const TapLaunch& L, int in_dtype, int acc_dtype, i
     } while (0)
     if (in_dtype == 0 && acc_dtype == 0) DAAM_LAUNCH(__half, __half);
     else if (in_dtype == 0 && acc_dtype == 1) DAAM_LAUNCH(__half, float);
-    else DAAM_LAUNCH(float, float);
+    else if (in_dtype == 2 && acc_dtype == 2) DAAM_LAUNCH(bf16_t, bf16_t);
+    else if (in_dtype == 2 && acc_dtype == 1) DAAM_LAUNCH(bf16_t, float);
+    else if (in_dtype == 1 && acc_dtype == 1) DAAM_LAUNCH(float, float);
+    else return hipErrorInvalidValue;
 #undef DAAM_LAUNCH
     return hipGetLastError();
 }
@@ -408,7 +415,7 @@ hipError_t launch_tap_generic(const TapLaunch& L, int in_dtype, int acc_dtype, i
 hipError_t launch_tap_probs(const ProbsLaunch& L, int in_dtype, int acc_dtype, hipStream_t stream, int* grid_out,
                             int* lds_out)
 {
-    const size_t lds = (size_t)kTapPixels * L.tokens * (in_dtype == 0 ? 2 : 4);
+    const size_t lds = (size_t)kTapPixels * L.tokens * (in_dtype == 1 ? 4 : 2);
     const int grid = L.wgs_per_xcd * 8;
     *grid_out = grid;
     *lds_out = (int)lds;
@@ -416,8 +423,14 @@ hipError_t launch_tap_probs(const ProbsLaunch& L, int in_dtype, int acc_dtype, h
         hipLaunchKernelGGL((tap_probs_kernel<__half, __half>), dim3(grid), dim3(256), lds, stream, L);
     else if (in_dtype == 0 && acc_dtype == 1)
         hipLaunchKernelGGL((tap_probs_kernel<__half, float>), dim3(grid), dim3(256), lds, stream, L);
-    else
+    else if (in_dtype == 2 && acc_dtype == 2)
+        hipLaunchKernelGGL((tap_probs_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), lds, stream, L);
+    else if (in_dtype == 2 && acc_dtype == 1)
+        hipLaunchKernelGGL((tap_probs_kernel<bf16_t, float>), dim3(grid), dim3(256), lds, stream, L);
+    else if (in_dtype == 1 && acc_dtype == 1)
         hipLaunchKernelGGL((tap_probs_kernel<float, float>), dim3(grid), dim3(256), lds, stream, L);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -431,6 +444,9 @@ hipError_t launch_finalize(const FinLaunch& L, int acc_dtype, hipStream_t stream
     if (acc_dtype == 0) {
         if ((e = allow_lds(finalize_kernel<__half>, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL((finalize_kernel<__half>), dim3(L.tokens, L.n_chunks), dim3(256), lds, stream, L);
+    } else if (acc_dtype == 2) {
+        if ((e = allow_lds(finalize_kernel<bf16_t>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((finalize_kernel<bf16_t>), dim3(L.tokens, L.n_chunks), dim3(256), lds, stream, L);
     } else {
         if ((e = allow_lds(finalize_kernel<float>, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL((finalize_kernel<float>), dim3(L.tokens, L.n_chunks), dim3(256), lds, stream, L);

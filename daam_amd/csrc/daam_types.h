@@ -88,4 +88,20 @@ struct FinLaunch {
     const void* mfma_ops;   // x2 MFMA finalize: [2 nt][64 lanes][6] 16-byte operand pieces (host-built), or NULL
 };
 
+// bfloat16 storage type (no arithmetic): values cross to f32 by a shift, back by round-to-nearest-even
+struct bf16_t { uint16_t bits; };
+__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+    union { uint32_t u; float f; } c;
+    c.u = (uint32_t)v.bits << 16;
+    return c.f;
+}
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    bf16_t r;
+    if ((c.u & 0x7fffffffu) > 0x7f800000u) { r.bits = (uint16_t)((c.u >> 16) | 0x0040u); return r; }   // NaN stays NaN
+    r.bits = (uint16_t)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
+    return r;
+}
+
 }  // namespace daam

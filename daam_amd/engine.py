@@ -20,6 +20,10 @@ from . import _native as nat
 
 Key = Tuple[int, int, int]   # (factor, layer, head) -- daam/heatmap.py:145
 
+# pipeline / running-sum dtypes the library knows (include/daam_hip.h).  fp16 runs on the MFMA kernels;
+# bf16 and fp32 on the any-shape kernels with the same rounding points.
+_DTYPE_CODE = {torch.float16: nat.DAAM_F16, torch.float32: nat.DAAM_F32, torch.bfloat16: nat.DAAM_BF16}
+
 
 class HeatMapEngine:
     def __init__(self, n_layers: int, tokens: int = 77, out_side: int = 64, accumulate: str = 'exact',
@@ -85,13 +89,13 @@ class HeatMapEngine:
     def _ensure_ctx(self, pipe_dtype: torch.dtype) -> None:
         if self.ctx is not None:
             return
-        if pipe_dtype not in (torch.float16, torch.float32):
-            raise RuntimeError(f'daam_amd: unsupported pipeline dtype {pipe_dtype} (fp16 / fp32 only)')
+        if pipe_dtype not in _DTYPE_CODE:
+            raise RuntimeError(f'daam_amd: unsupported pipeline dtype {pipe_dtype} (fp16 / bf16 / fp32 only)')
         self.acc_dtype = torch.float32 if self.accumulate == 'float32' else pipe_dtype
         ctx = nat.c_void_p()
         with torch.cuda.device(self.device):
             nat.check(self.lib.daam_ctx_create(self.n_layers, self.tokens, self.out_side,
-                                               nat.DAAM_F16 if self.acc_dtype == torch.float16 else nat.DAAM_F32,
+                                               _DTYPE_CODE[self.acc_dtype],
                                                nat.byref(ctx)))
         self.ctx = ctx
 
@@ -224,8 +228,11 @@ class HeatMapEngine:
         self._ensure_ctx(query.dtype)
         if query.dtype != key.dtype:
             raise RuntimeError('daam_amd: query / key dtype mismatch')
-        if query.dtype == torch.float32 and self.acc_dtype == torch.float16:
-            raise RuntimeError('daam_amd: fp32 activations on a trace whose running sums are fp16')
+        if query.dtype not in _DTYPE_CODE:
+            raise RuntimeError(f'daam_amd: unsupported activation dtype {query.dtype} (fp16 / bf16 / fp32 only)')
+        if self.acc_dtype not in (torch.float32, query.dtype):
+            raise RuntimeError(f'daam_amd: {query.dtype} activations on a trace whose running sums are {self.acc_dtype} '
+                               '(fp32 activations need fp32 sums; fp16 / bf16 sums need activations of the same dtype)')
         b, hw, c = query.shape
         tokens = key.shape[1]
         d = c // heads
@@ -233,7 +240,7 @@ class HeatMapEngine:
         bh = b * heads
         self._ensure_layer(layer, bh - bh // 2, side, factor)
         desc = nat.QKDesc(
-            in_dtype=nat.DAAM_F16 if query.dtype == torch.float16 else nat.DAAM_F32,
+            in_dtype=_DTYPE_CODE[query.dtype],
             batch=b, heads=heads, hw=hw, tokens=tokens, head_dim=d, round_logits=1 if round_logits else 0,
             scale=float(scale),
             q_stride_b=hw * c, q_stride_h=d, q_stride_p=c,
@@ -297,7 +304,7 @@ class HeatMapEngine:
         bh, hw, tokens = probs.shape
         self._ensure_layer(layer, bh - bh // 2, int(math.sqrt(hw)), factor)
         nat.check(self.lib.daam_tap_probs(self.ctx, layer, probs.data_ptr(),
-                                          nat.DAAM_F16 if probs.dtype == torch.float16 else nat.DAAM_F32,
+                                          _DTYPE_CODE[probs.dtype],
                                           bh, hw, tokens, self.stream))
         self._touch(layer)
 

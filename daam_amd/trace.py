@@ -33,8 +33,21 @@ def _default_defer() -> int:
     return int(os.environ.get('DAAM_DEFER_STEPS', '64'))
 
 
-def _default_defer_bytes() -> int:
-    return int(os.environ.get('DAAM_DEFER_BYTES', str(32 << 30)))
+def _default_defer_bytes(pipeline=None) -> int:
+    """Bytes of recorded Q / K a trace may keep alive between tap launches: ``$DAAM_DEFER_BYTES``, else
+    32 GiB, but never more than a quarter of the device memory that is free when the trace is set up."""
+    env = os.environ.get('DAAM_DEFER_BYTES')
+    if env:
+        return int(env)
+    budget = 32 << 30
+    try:
+        dev = next(pipeline.unet.parameters()).device
+        if dev.type == 'cuda':
+            free, _ = torch.cuda.mem_get_info(dev)
+            budget = min(budget, max(free // 4, 1 << 30))
+    except Exception:                                   # no parameters / no device yet: keep the default
+        pass
+    return budget
 
 
 class DiffusionHeatMapHooker(AggregateHooker):
@@ -60,7 +73,7 @@ class DiffusionHeatMapHooker(AggregateHooker):
         self.engine = HeatMapEngine(max(1, len(modules_found)), tokens=77, out_side=int(math.sqrt(self.latent_hw)),
                                     accumulate=accumulate,
                                     defer_steps=_default_defer() if defer_steps is None else defer_steps,
-                                    defer_bytes=_default_defer_bytes())
+                                    defer_bytes=_default_defer_bytes(pipeline))
         self.all_heat_maps = RawHeatMapCollection(self.engine)
         self.last_prompt: str = ''
         self.last_image = None

@@ -40,6 +40,7 @@ extern "C" {
 /* element types of activations (q, k, probs) and of the running sums */
 #define DAAM_F16 0
 #define DAAM_F32 1
+#define DAAM_BF16 2         /* bfloat16 pipelines: any-shape kernels (no MFMA tap yet), same rounding points */
 
 /* DAAM_E_* */
 #define DAAM_E_INVALID   (-1)   /* bad argument / shape / dtype */
@@ -57,7 +58,7 @@ typedef struct DaamCtx DaamCtx;
  * The reference keeps batch*heads indices [BH/2, BH) (trace.py:240): with classifier-free
  * guidance (batch 2) that is the conditional prompt, all heads. */
 typedef struct DaamQKDesc {
-    int32_t in_dtype;        /* DAAM_F16 | DAAM_F32: dtype of q and k (the pipeline dtype) */
+    int32_t in_dtype;        /* DAAM_F16 | DAAM_F32 | DAAM_BF16: dtype of q and k (the pipeline dtype) */
     int32_t batch;           /* B */
     int32_t heads;           /* H */
     int32_t hw;              /* query positions = h*w, square (trace.py:233) */

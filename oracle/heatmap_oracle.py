@@ -19,6 +19,10 @@ Numeric modes (``pipe_dtype``):
                     rounded to fp16, running sums kept in fp16 (``heatmap.py:150,156`` --
                     ``add`` has no autocast rule), bicubic / clamp / mean in fp32
                     (autocast FP32 policy, ``trace.py:111``).
+  * ``'bfloat16'`` -- literal bf16 pipeline, same rounding points as fp16 (bf16 logits,
+                    probabilities and running sums).  numpy has no bfloat16: such arrays are carried
+                    as float32 holding bf16-representable values (``round_bf16``); an f32 add of two
+                    of them followed by one rounding IS the correctly rounded bf16 add.
   * ``float64``  -- ground truth (no intermediate rounding) for accuracy reporting.
 ``acc_dtype`` may override the running-sum type (the ``f32`` accuracy mode of the kernels).
 """
@@ -33,6 +37,23 @@ Key = Tuple[int, int, int]          # (factor, layer, head) -- heatmap.py:145
 
 _BICUBIC_A = -0.75                  # torch upsample_bicubic2d constant
 
+BF16 = 'bfloat16'
+
+
+def is_bf16(dt) -> bool:
+    return isinstance(dt, str) and dt == BF16
+
+
+def round_bf16(x) -> np.ndarray:
+    """float32 -> nearest bfloat16 (ties to even), returned as float32."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)
+    return r.view(np.float32).reshape(np.shape(x))
+
+
+def _cast(x: np.ndarray, dt) -> np.ndarray:
+    return round_bf16(x) if is_bf16(dt) else x.astype(dt)
+
 
 # --------------------------------------------------------------------------------------
 # K1 / K2: diffusers Attention.get_attention_scores as called at trace.py:276
@@ -44,7 +65,8 @@ def attention_probs(q: np.ndarray, k: np.ndarray, scale: float, pipe_dtype=np.fl
     (diffusers 0.21.2 ``get_attention_scores``: ``baddbmm(beta=0, alpha=scale)`` ->
     ``softmax(dim=-1)`` -> ``.to(dtype)``; SURVEY Appendix A.)
     """
-    pipe_dtype = np.dtype(pipe_dtype)
+    if not is_bf16(pipe_dtype):
+        pipe_dtype = np.dtype(pipe_dtype)
     if pipe_dtype == np.float64:
         logits = np.einsum('bpd,btd->bpt', q.astype(np.float64), k.astype(np.float64)) * float(scale)
         m = logits.max(-1, keepdims=True)
@@ -52,12 +74,12 @@ def attention_probs(q: np.ndarray, k: np.ndarray, scale: float, pipe_dtype=np.fl
         return e / e.sum(-1, keepdims=True)
     # fp32 accumulate, alpha applied in fp32, result rounded to the pipe dtype
     acc = np.matmul(q.astype(np.float32), np.swapaxes(k.astype(np.float32), -1, -2))
-    logits = (acc * np.float32(scale)).astype(pipe_dtype)
+    logits = _cast(acc * np.float32(scale), pipe_dtype)
     x = logits.astype(np.float32)
     m = x.max(-1, keepdims=True)
     e = np.exp(x - m, dtype=np.float32)
     p = e / e.sum(-1, keepdims=True, dtype=np.float32)
-    return p.astype(pipe_dtype)
+    return _cast(p, pipe_dtype)
 
 
 # --------------------------------------------------------------------------------------
@@ -91,16 +113,19 @@ class RawMaps:
     """Insertion-ordered ``(factor, layer, head) -> running sum [T, h, w]``."""
 
     def __init__(self, acc_dtype=np.float32):
-        self.acc_dtype = np.dtype(acc_dtype)
+        self.acc_dtype = acc_dtype if is_bf16(acc_dtype) else np.dtype(acc_dtype)
         self.maps: Dict[Key, np.ndarray] = {}
 
     def update(self, factor: int, layer: int, head: int, heat_map: np.ndarray):
         key = (factor, layer, head)
         prev = self.maps.get(key)
-        add = heat_map.astype(self.acc_dtype)
+        add = _cast(heat_map, self.acc_dtype)
         # out-of-place ``acc = acc + map`` in the accumulator dtype (heatmap.py:156).
         # numpy's float16 add computes in fp32 and rounds once (RNE) == torch's fp16 add.
-        self.maps[key] = add.copy() if prev is None else prev + add
+        if prev is None:
+            self.maps[key] = add.copy()
+        else:
+            self.maps[key] = round_bf16(prev + add) if is_bf16(self.acc_dtype) else prev + add
 
     def clear(self):
         self.maps.clear()
@@ -271,8 +296,9 @@ def replay_generation(pipe, steps: int, pipe_dtype, acc_dtype=None, restrict=Non
     (``oracle/fake_diffusers.py``): per step, every cross-attention in execution order;
     hooked ones (per ``locate``) are tapped with ``layer_idx`` = locator position."""
     import torch
-    np_dtype = {torch.float16: np.float16, torch.float32: np.float32,
+    np_dtype = {torch.float16: np.float16, torch.float32: np.float32, torch.bfloat16: BF16,
                 torch.float64: np.float64}.get(pipe_dtype, pipe_dtype)
+    as_np = (lambda t: t.float().cpu().numpy()) if is_bf16(np_dtype) else (lambda t: t.cpu().numpy())
     raw = RawMaps(np_dtype if acc_dtype is None else acc_dtype)
     modules, _ = locate(pipe.unet, restrict, locate_middle_block)
     index_of = {id(m): i for i, m in enumerate(modules)}
@@ -284,7 +310,7 @@ def replay_generation(pipe, steps: int, pipe_dtype, acc_dtype=None, restrict=Non
             if li is None:
                 continue
             a = spec.module
-            q = a.head_to_batch_dim(a.to_q(pipe.hidden_states(i, spec, step))).cpu().numpy()
-            k = a.head_to_batch_dim(a.to_k(pipe.context(i, spec))).cpu().numpy()
+            q = as_np(a.head_to_batch_dim(a.to_q(pipe.hidden_states(i, spec, step))))
+            k = as_np(a.head_to_batch_dim(a.to_k(pipe.context(i, spec))))
             tap(raw, li, q, k, a.scale, lat, np_dtype)
     return raw

@@ -45,6 +45,9 @@ CASES = {
     # same topology, literal fp16 pipeline, more steps so fp16 running sums round
     'sd15_f16': dict(kind='sd15', dtype='float16', batch=2, steps=12, prompt='a dog', seed=12,
                      unet=dict(dim_head=16)),
+    # literal bf16 pipeline (bf16 logits / probabilities / running sums)
+    'sd15_bf16': dict(kind='sd15', dtype='bfloat16', batch=2, steps=12, prompt='a dog', seed=18,
+                      unet=dict(dim_head=16), variants=['default', 'normalize', 'factor_hi']),
     # SDXL topology (60 layers -> capped transformer blocks, fewer heads), factors {1,2}
     'sdxl_f32': dict(kind='sdxl', dtype='float32', batch=2, steps=2, prompt='a photo of a monkey', seed=13,
                      unet=dict(dim_head=8, heads_scale=0.2, tblocks_cap=2)),
@@ -99,7 +102,7 @@ def run_case(name, spec, daam):
         out['raw_sample_ids'] = np.asarray(sample_ids, dtype=np.int32)
         for sid in sample_ids:
             out[f'raw_{sid}'] = items[sid][1][SAMPLE_TOKENS].float().numpy()
-        if dtype == torch.float16:
+        if dtype in (torch.float16, torch.bfloat16):
             # emulate CUDA autocast(float32): upsample_bicubic2d is on the FP32 policy list
             hm = tc.all_heat_maps.ids_to_heatmaps
             for k in list(hm.keys()):

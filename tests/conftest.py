@@ -31,7 +31,7 @@ def golden_pipe(meta, device='cpu'):
                         mini=True, identity_proj=True, **meta['unet'])
 
 
-GOLDEN_CASES = ['sd15_f32', 'sd15_f16', 'sdxl_f32', 'sdxl_f16', 'sdxl2048_f32', 'sd15_nocfg_f32', 'sd15_b4_f32']
+GOLDEN_CASES = ['sd15_f32', 'sd15_f16', 'sd15_bf16', 'sdxl_f32', 'sdxl_f16', 'sdxl2048_f32', 'sd15_nocfg_f32', 'sd15_b4_f32']
 
 
 @pytest.fixture(params=GOLDEN_CASES)

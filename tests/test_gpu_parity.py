@@ -7,6 +7,8 @@ MI355X.  Tolerances are stated next to each comparison:
         raw running sums ............ <= 1 ulp of the sum (a logit straddling an fp16 rounding
                                       boundary moves one probability by one ulp)
         global heat maps ............ <= 1e-3 max-abs (BASELINE.json north_star); observed ~1e-4
+  * bf16 pipeline, bf16 sums: the same statements with 8-bit significands (1 ulp = 2^-8 relative); global
+        heat maps <= 1e-2 max-abs (the bf16 reference differs from the fp32 one by that order itself)
   * probabilities path (tap='probs') . bit-exact running sums (same adds, same order)
 """
 import json
@@ -31,10 +33,19 @@ def _engine(n_layers=4, **kw):
 
 
 def _qk(rng, batch, heads, hw, d, dtype, sos_gain=3.0):
+    """dtype: a numpy dtype, or ho.BF16 (then float32 arrays holding bf16-representable values)."""
     q = rng.standard_normal((batch, hw, heads * d)).astype(np.float32)
     k = rng.standard_normal((batch, 77, heads * d)).astype(np.float32)
     k[:, 0, :] *= sos_gain
+    if ho.is_bf16(dtype):
+        return ho.round_bf16(q), ho.round_bf16(k)
     return q.astype(dtype), k.astype(dtype)
+
+
+def _dev(x, dtype=None):
+    """numpy -> device tensor; bf16 data travels as float32 and is narrowed (exactly) on the device."""
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t.to(torch.bfloat16) if ho.is_bf16(dtype) else t
 
 
 def _to_bh(x, heads):
@@ -64,34 +75,35 @@ SHAPES = [
 
 
 @pytest.mark.parametrize('shape', SHAPES)
-@pytest.mark.parametrize('mode', ['f16_exact', 'f16_f32acc', 'f32'])
+@pytest.mark.parametrize('mode', ['f16_exact', 'f16_f32acc', 'f32', 'bf16_exact', 'bf16_f32acc'])
 @pytest.mark.parametrize('defer', [0, 3])
 def test_tap_qk_vs_oracle(shape, mode, defer):
     batch, heads, side, d = shape
     hw = side * side
     steps = 4
     rng = np.random.default_rng(sum(shape) * 7 + len(mode))
-    np_dt = np.float32 if mode == 'f32' else np.float16
-    acc_np = np.float16 if mode == 'f16_exact' else np.float32
+    np_dt = np.float32 if mode == 'f32' else ho.BF16 if mode.startswith('bf16') else np.float16
+    acc_np = np_dt if mode.endswith('_exact') else np.float32
     scale = d ** -0.5
     qs, ks = zip(*[_qk(rng, batch, heads, hw, d, np_dt) for _ in range(steps)])
     want = _oracle_steps(qs, ks, heads, scale, np_dt, acc_np).astype(np.float64)
 
-    eng = _engine(accumulate='exact' if mode != 'f16_f32acc' else 'float32', defer_steps=defer)
+    eng = _engine(accumulate='exact' if not mode.endswith('_f32acc') else 'float32', defer_steps=defer)
     for q, k in zip(qs, ks):
-        eng.tap_qk(0, torch.from_numpy(q).to(DEV), torch.from_numpy(k).to(DEV), heads, scale, factor=1)
+        eng.tap_qk(0, _dev(q, np_dt), _dev(k, np_dt), heads, scale, factor=1)
     got = np.stack([v.float().cpu().numpy() for _, v in eng.items()]).astype(np.float64)
     assert got.shape == want.shape
+    half_ulp = 2.0 ** -8 if mode.startswith('bf16') else 2.0 ** -11      # of a probability <= 1
     if mode == 'f32':
         tol = 2e-6 * max(1.0, np.abs(want).max())
-    elif mode == 'f16_exact':
-        tol = 2.0 ** -10 * max(1.0, want.max())          # 1 ulp of the largest fp16 running sum
+    elif mode.endswith('_exact'):
+        tol = 2 * half_ulp * max(1.0, want.max())         # 1 ulp of the largest running sum
     else:
-        tol = steps * 2.0 ** -11                          # one flipped fp16 probability ulp per step
+        tol = steps * half_ulp                            # one flipped probability ulp per step
     err = np.abs(got - want).max()
     assert err <= tol, f'{shape} {mode} defer={defer}: max-abs {err} > {tol}'
     # every step's probabilities sum to one over the tokens
-    np.testing.assert_allclose(got.sum(1), steps, atol=steps * 77 * 2.0 ** -11)
+    np.testing.assert_allclose(got.sum(1), steps, atol=steps * 77 * half_ulp)
     eng.close()
 
 
@@ -131,10 +143,10 @@ def test_deferred_equals_immediate_bits(steps, d):
         assert torch.equal(res[0], r)
 
 
-@pytest.mark.parametrize('dt', ['float16', 'float32'])
+@pytest.mark.parametrize('dt', ['float16', 'float32', 'bfloat16'])
 def test_tap_probs_bit_exact(dt):
     rng = np.random.default_rng(3)
-    np_dt = np.dtype(dt)
+    np_dt = ho.BF16 if dt == 'bfloat16' else np.dtype(dt)
     heads, hw, steps = 3, 144, 5                          # hw = 12*12: not a multiple of the 64-pixel tile
     raw = ho.RawMaps(np_dt)
     eng = _engine()
@@ -142,10 +154,11 @@ def test_tap_probs_bit_exact(dt):
         q, k = _qk(rng, 2, heads, hw, 16, np_dt)
         probs = ho.attention_probs(_to_bh(q, heads), _to_bh(k, heads), 0.25, np_dt)
         ho.tap(raw, 2, None, None, 0.25, latent_hw=4096, pipe_dtype=np_dt, probs=probs)
-        eng.tap_probs(2, torch.from_numpy(probs).to(DEV), factor=5)
+        eng.tap_probs(2, _dev(probs, np_dt), factor=5)
     want = np.stack([v for _, v in raw])
-    got = torch.stack([v for _, v in eng.items()]).cpu().numpy()
-    assert got.dtype == want.dtype
+    got = torch.stack([v for _, v in eng.items()])
+    assert str(got.dtype) == f'torch.{dt}'
+    got = got.float().cpu().numpy() if dt == 'bfloat16' else got.cpu().numpy()
     np.testing.assert_array_equal(got, want)
     assert [k for k, _ in eng.items()] == [(5, 2, h) for h in range(heads)]
     eng.close()
@@ -211,7 +224,8 @@ def test_normalize_and_word_maps():
 # end to end through the reference's API against the golden vectors of the unmodified reference
 # ---------------------------------------------------------------------------------------------
 def _global_tol(meta):
-    return 2e-6 if meta['dtype'] == 'float32' else 1e-3       # north_star: <= 1e-3 max-abs in fp16
+    # north_star: <= 1e-3 max-abs in fp16; bf16 carries 3 bits less
+    return {'float32': 2e-6, 'float16': 1e-3, 'bfloat16': 8e-3}[meta['dtype']]
 
 
 @pytest.mark.parametrize('tap,defer', [('qk', 0), ('qk', 2), ('qk', 50), ('probs', 0)])
@@ -226,11 +240,12 @@ def test_trace_api_matches_reference_golden(golden_case, tap, defer):
         np.testing.assert_array_equal(keys, z['keys'])              # same keys, same first-update order
         assert str(items[0][1].dtype) == str(z['raw_dtype'])
         sums = np.asarray([float(v.double().sum()) for _, v in items])
-        np.testing.assert_allclose(sums, z['key_sum'], rtol=2e-4 if meta['dtype'] == 'float16' else 1e-5)
+        np.testing.assert_allclose(sums, z['key_sum'], rtol={'float32': 1e-5, 'float16': 2e-4, 'bfloat16': 2e-3}[meta['dtype']])
         for sid in z['raw_sample_ids']:
             got = items[int(sid)][1][SAMPLE_TOKENS].float().cpu().numpy()
             want = z[f'raw_{int(sid)}']
-            tol = 2e-6 if meta['dtype'] == 'float32' else 2.0 ** -10 * max(1.0, float(want.max()))
+            ulp = {'float16': 2.0 ** -10, 'bfloat16': 2.0 ** -7}.get(meta['dtype'])
+            tol = 2e-6 if ulp is None else ulp * max(1.0, float(want.max()))
             np.testing.assert_allclose(got, want, rtol=0, atol=tol)
         for vn, kw in json.loads(str(z['variants'])).items():
             got = tc.compute_global_heat_map(**kw).heat_maps
@@ -248,7 +263,7 @@ def test_trace_api_matches_reference_golden(golden_case, tap, defer):
         # min-max normalisation divides by the range of the word map: scale the tolerance with it
         span = float(z['word_map'].max() - z['word_map'].min())
         np.testing.assert_allclose(whm.expand_as(_Img()).numpy(), z['word_expand_128'], rtol=0,
-                                   atol=max(2e-5, 4 * _global_tol(meta) / max(span, 1e-6)) if meta['dtype'] == 'float16'
+                                   atol=max(2e-5, 4 * _global_tol(meta) / max(span, 1e-6)) if meta['dtype'] != 'float32'
                                    else 5e-5)
         np.testing.assert_allclose(whm.expand_as(_Img(), absolute=True).numpy(), z['word_expand_128_abs'], rtol=0,
                                    atol=max(2e-5, _global_tol(meta)))

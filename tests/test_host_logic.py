@@ -301,12 +301,16 @@ def test_engine_immediate_mode_and_dtype_rules(fake_engine):
     assert eng.acc_dtype == torch.float16 and eng.acc[0].shape == (2, 77, 8, 8)
     with pytest.raises(RuntimeError, match='fp32 activations'):
         eng.tap_qk(1, torch.zeros(2, 64, 16), torch.zeros(2, 77, 16), 2, 0.35, 1)
+    with pytest.raises(RuntimeError, match='running sums are torch.float16'):      # bf16 into fp16 sums
+        eng.tap_qk(1, torch.zeros(2, 64, 16, dtype=torch.bfloat16), torch.zeros(2, 77, 16, dtype=torch.bfloat16), 2, 0.35, 1)
+    engb = E.HeatMapEngine(1)
+    engb.tap_qk(0, torch.zeros(2, 64, 16, dtype=torch.bfloat16), torch.zeros(2, 77, 16, dtype=torch.bfloat16), 2, 0.35, 1)
+    assert engb.acc_dtype == torch.bfloat16 and engb.acc[0].dtype == torch.bfloat16
+    with pytest.raises(RuntimeError, match='unsupported pipeline dtype'):
+        E.HeatMapEngine(1).tap_qk(0, torch.zeros(2, 64, 16, dtype=torch.float64), torch.zeros(2, 77, 16, dtype=torch.float64), 2, 0.35, 1)
     eng32 = E.HeatMapEngine(1, accumulate='float32')
     eng32.tap_probs(0, torch.zeros(4, 64, 77, dtype=torch.float16), factor=1)
     assert eng32.acc_dtype == torch.float32
-    with pytest.raises(RuntimeError, match='unsupported pipeline dtype'):
-        E.HeatMapEngine(1).tap_qk(0, torch.zeros(2, 64, 16, dtype=torch.bfloat16),
-                                  torch.zeros(2, 77, 16, dtype=torch.bfloat16), 2, 0.35, 1)
     with pytest.raises(ValueError):
         E.HeatMapEngine(1, accumulate='bf16')
 
