@@ -1,4 +1,5 @@
-// fp16 tap for head_dim = 64 (every SDXL layer), gfx950, built on v_mfma_f32_16x16x32_f16.
+// fp16 tap for head_dim <= 64 (64: every SDXL / SD-2.x layer; 40: the 64x64 layers of SD-v1.5, zero-padded
+// to 64), gfx950, built on v_mfma_f32_16x16x32_f16.
 //
 // Why a second tiling: with 32x32 MFMA tiles a lane owns one pixel and 40 token slots, so the
 // softmax state (logits, exponentials, running sums) plus three 16-register accumulator tiles push
@@ -218,10 +219,20 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_ker
         for (int i = 0; i < kSlots16; ++i) { run0[i >> 1][i & 1] = (ACC_T)0; run1[i >> 1][i & 1] = (ACC_T)0; }
     }
     __syncthreads();                                          // staging reads done; sptr visible
-    // K rows 77..79 (never written by a step) must be finite: zero them once, both buffers
-    for (int i = tid; i < 2 * 3 * (kD64Row / 16); i += 256) {
-        const int buf = i / (3 * (kD64Row / 16)), r = i % (3 * (kD64Row / 16));
-        *reinterpret_cast<float4v*>(kbuf + buf * kD64KBuf + kTok * kD64Row + r * 16) = float4v{0, 0, 0, 0};
+    // head_dim < 64 (multiple of 8; SD-v1.5's 40): the contraction runs over 64 with zeros beyond head_dim --
+    // K pieces past it are never written (the buffers are zeroed once), the lanes' Q pieces past it are
+    // fetched from a valid address and cleared before the MFMAs.
+    const int d = lay.head_dim;
+    const bool partial = d < 64;                              // wave-uniform
+    if (partial) {
+        for (int i = tid; i < 2 * kD64KBuf / 16; i += 256)
+            *reinterpret_cast<float4v*>(kbuf + i * 16) = float4v{0, 0, 0, 0};
+    } else {
+        // K rows 77..79 (never written by a step) must be finite: zero them once, both buffers
+        for (int i = tid; i < 2 * 3 * (kD64Row / 16); i += 256) {
+            const int buf = i / (3 * (kD64Row / 16)), r = i % (3 * (kD64Row / 16));
+            *reinterpret_cast<float4v*>(kbuf + buf * kD64KBuf + kTok * kD64Row + r * 16) = float4v{0, 0, 0, 0};
+        }
     }
 
     // per-thread K piece coordinates: piece c = tid + 256 j2 -> row c / 8, piece c % 8
@@ -230,12 +241,15 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_ker
     for (int j2 = 0; j2 < KCH; ++j2) {
         const int c = tid + 256 * j2;
         const int t = c >> 3, ch = c & 7;
-        k_src[j2] = min(t, kTok - 1) * (int)lay.k_st + ch * 8;
-        k_dst[j2] = t < kTok ? t * kD64Row + ch * 16 : -1;
+        const bool in_row = ch * 8 < d;                       // piece inside the head's d elements
+        k_src[j2] = min(t, kTok - 1) * (int)lay.k_st + (in_row ? ch * 8 : 0);
+        k_dst[j2] = (t < kTok && in_row) ? t * kD64Row + ch * 16 : -1;
     }
     const int px0 = min(p0 + wave * 32 + j, lay.hw - 1), px1 = min(p0 + wave * 32 + 16 + j, lay.hw - 1);
-    const int64_t q_row0 = q_off + (int64_t)px0 * lay.q_sp + h * 8;
-    const int64_t q_row1 = q_off + (int64_t)px1 * lay.q_sp + h * 8;
+    const bool qv0 = 8 * h < d, qv1 = 32 + 8 * h < d;         // this lane's piece of k-step 0 / 1 exists
+    const int qo0 = qv0 ? 8 * h : 0, qo1 = qv1 ? 32 + 8 * h : 0;
+    const int64_t q_row0 = q_off + (int64_t)px0 * lay.q_sp;
+    const int64_t q_row1 = q_off + (int64_t)px1 * lay.q_sp;
 
     float4v kreg[KCH];
     half8 bq0[2], bq1[2];
@@ -251,10 +265,10 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_ker
     };
     auto issue_q = [&](int s) {
         const _Float16* qp = reinterpret_cast<const _Float16*>(sptr[2 * s]);
-        bq0[0] = *as_global<half8>(qp + q_row0);
-        bq0[1] = *as_global<half8>(qp + q_row0 + 32);
-        bq1[0] = *as_global<half8>(qp + q_row1);
-        bq1[1] = *as_global<half8>(qp + q_row1 + 32);
+        bq0[0] = *as_global<half8>(qp + q_row0 + qo0);
+        bq0[1] = *as_global<half8>(qp + q_row0 + qo1);
+        bq1[0] = *as_global<half8>(qp + q_row1 + qo0);
+        bq1[1] = *as_global<half8>(qp + q_row1 + qo1);
     };
     const unsigned char* a_rd = kbuf + j * kD64Row + h * 16;  // + buf * kD64KBuf + mt * 16 rows + ks * 64
 
@@ -264,6 +278,11 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_ker
     for (int s = 0; s < n_steps; ++s) {
         __syncthreads();
         const unsigned char* kb = a_rd + (s & 1) * kD64KBuf;
+        if (partial) {
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (!qv0) { bq0[0] = z; bq1[0] = z; }
+            if (!qv1) { bq0[1] = z; bq1[1] = z; }
+        }
         floatx4 c0[5], c1[5];
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
@@ -304,7 +323,7 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_ker
 bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                        const void* q, const void* k)
 {
-    if (head_dim != 64) return false;
+    if (head_dim < 8 || head_dim > 64 || head_dim % 8 != 0) return false;
     const int64_t s[] = {q_sp, k_st, q_sb, q_sh, k_sb, k_sh};
     for (int64_t v : s)
         if (v % 8 != 0) return false;
