@@ -52,9 +52,7 @@ class HeatMapEngine:
         self.touched: List[int] = []                     # layers updated since clear(), first-update order
         # deferred taps: recorded per call (the tensors are kept alive until the flush)
         self._rec: List[tuple] = []                      # (layer, query, key, address of its DaamQKDesc)
-        # steps per launch; $DAAM_FIRST_WINDOW shortens the first launch after clear() (an experiment knob:
-        # it lets the GPU start while a slow host is still recording, at the price of one more launch)
-        self._window = self._first_window()
+        self._window = self.defer_steps                  # steps of one layer per launch
         self._cnt: List[int] = [0] * self.n_layers      # recorded steps per layer
         self._qk_cache: List[Optional[tuple]] = [None] * self.n_layers
         self._touched_flag: List[bool] = [False] * self.n_layers
@@ -145,7 +143,7 @@ class HeatMapEngine:
         self._drop_recorded()
         self.touched.clear()
         self._touched_flag = [False] * self.n_layers
-        self._set_window(self._first_window())
+        self._set_window(self.defer_steps)
         if self._fast is not None:
             self._fast.reset_touched()
         if self.ctx is not None:
@@ -253,9 +251,6 @@ class HeatMapEngine:
                  (query.numel() + key.numel()) * query.element_size())
         self._qk_cache[layer] = entry
         return query, key, entry
-
-    def _first_window(self) -> int:
-        return max(1, min(self.defer_steps, int(os.environ.get('DAAM_FIRST_WINDOW', 64)))) if self.defer_steps else 0
 
     def flush(self) -> None:
         """Run every recorded (deferred) tap; the held Q/K references are dropped afterwards
