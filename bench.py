@@ -237,8 +237,17 @@ def main():
     eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=args.accumulate, defer_steps=args.defer)
 
     calls = call_lists(layers, sets, latent_side)
-    for _ in range(args.warmup):
+    # untimed: the W warm-up generations, plus whatever it takes to reach steady state -- the first call
+    # creates the context and loads the code objects (36 ms), the GPU needs ~10 generations from idle to its
+    # sustained clock, and the one-off costs of the result stack / the RCCL communicator are paid here too
+    warm = [one_generation(eng, calls, args.denoise_steps) for _ in range(max(args.warmup, 1))]
+    for _ in range(max(0, 20 - len(warm))):
         one_generation(eng, calls, args.denoise_steps)
+    w = torch.stack(warm[:2])
+    if dist:
+        gathered = torch.empty(world * w.shape[0], *w.shape[1:], device=device, dtype=w.dtype)
+        dist.all_gather_into_tensor(gathered, w)
+    del warm, w
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
