@@ -75,8 +75,9 @@ typedef struct DaamQKDesc {
  * One context per trace object per device (reference: one RawHeatMapCollection per
  * DiffusionHeatMapHooker, trace.py:31).  tokens = context_size (77, trace.py:194);
  * out_side = int(sqrt(latent_hw)) (64, or 96 for 768-px SD-2.x; trace.py:32-33,109);
- * acc_dtype = dtype of the running sums: DAAM_F16 reproduces the reference's fp16 sums on an
- * fp16 pipeline bit-for-bit in the add (heatmap.py:156), DAAM_F32 is the accuracy mode. */
+ * acc_dtype = dtype of the running sums: DAAM_F16 / DAAM_BF16 reproduce the reference's fp16 / bf16
+ * sums on an fp16 / bf16 pipeline bit-for-bit in the add (heatmap.py:156), DAAM_F32 is the accuracy
+ * mode.  Activations must have the dtype of the sums, or the sums must be DAAM_F32. */
 int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, DaamCtx** out);
 int daam_ctx_destroy(DaamCtx* ctx);
 
