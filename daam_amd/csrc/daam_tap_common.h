@@ -115,32 +115,43 @@ __device__ __forceinline__ void softmax_accumulate(const floatx16& c0, const flo
                 xh[18][1] = ninf;
                 xh[19] = half2v{ninf, ninf};
             }
-            half2v ma = xh[0], mb = xh[1];
-#pragma unroll
-            for (int i = 2; i < kSlots / 2; i += 2) {
-                ma = pk_max(ma, xh[i]);
-                mb = pk_max(mb, xh[i + 1]);
-            }
-            ma = pk_max(ma, mb);
-            float m = fmaxf((float)ma[0], (float)ma[1]);
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
             const float L = 1.44269502162933349609375f;
-            const float nmL = -m * L;
-            float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
             float2v ev[kSlots / 2];
+            auto exps = [&](float nmL) -> float {                        // e = 2^(x L - m L), returns the pixel's sum
+                float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < kSlots / 2; i += 2) {
-                ev[i] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][0], L, nmL)),
-                                __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][1], L, nmL))};
-                ev[i + 1] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][0], L, nmL)),
-                                    __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][1], L, nmL))};
-                sa += ev[i];
-                sb += ev[i + 1];
+                for (int i = 0; i < kSlots / 2; i += 2) {
+                    ev[i] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][0], L, nmL)),
+                                    __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][1], L, nmL))};
+                    ev[i + 1] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][0], L, nmL)),
+                                        __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][1], L, nmL))};
+                    sa += ev[i];
+                    sb += ev[i + 1];
+                }
+                sa += sb;
+                const float sum = sa[0] + sa[1];
+                return sum + __shfl_xor(sum, 32, 64);
+            };
+            // Reference point = token 0's logit (lane half 0, slot 0; its own term is exactly 1, so the sum cannot
+            // underflow) instead of the row maximum -- softmax is shift-invariant.  Only when some logit exceeds it
+            // by more than ~69 (sum > 2^100: 1/sum would leave the normal f32 range; past 88 the exponentials
+            // overflow) is the row redone with the true maximum, as the reference does.
+            const auto x0 = __builtin_amdgcn_permlane32_swap(__float_as_uint((float)xh[0][0]), __float_as_uint((float)xh[0][0]),
+                                                             false, false);      // x0[0] = lanes (lo, lo)
+            float tot = exps(-__uint_as_float(x0[0]) * L);
+            if (__builtin_expect(!(tot <= 0x1p100f), 0)) {               // large, inf or NaN
+                half2v ma = xh[0], mb = xh[1];
+#pragma unroll
+                for (int i = 2; i < kSlots / 2; i += 2) {
+                    ma = pk_max(ma, xh[i]);
+                    mb = pk_max(mb, xh[i + 1]);
+                }
+                ma = pk_max(ma, mb);
+                float m = fmaxf((float)ma[0], (float)ma[1]);
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                tot = exps(-m * L);
             }
-            sa += sb;
-            float sum = sa[0] + sa[1];
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = __builtin_amdgcn_rcpf(sum);                  // v_rcp_f32: 1 ulp
+            const float inv = __builtin_amdgcn_rcpf(tot);                  // v_rcp_f32: 1 ulp
 #pragma unroll
             for (int i = 0; i < kSlots / 2; ++i) {
                 const half2v ph = cvt_pk_rne(ev[i] * inv);                // probs.to(dtype)

@@ -46,6 +46,12 @@ __device__ __forceinline__ float quad_max(float v) {
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
+// value of lane quarter 0 (lanes 0..15 = the lanes holding token 0) of each pixel, in all four of its lanes
+__device__ __forceinline__ float quad_bcast0(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);   // r[0] = rows (0, 0, 2, 2)
+    r = __builtin_amdgcn_permlane32_swap(r[0], r[0], false, false);                                    // r[0] = rows (0, 0, 0, 0)
+    return __uint_as_float(r[0]);
+}
 __device__ __forceinline__ float quad_sum(float v) {
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -90,29 +96,40 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
             xh[8][1] = ninf;
             xh[9] = half2v{ninf, ninf};
         }
-        half2v ma = xh[0], mb = xh[1];
-#pragma unroll
-        for (int i = 2; i < kSlots16 / 2; i += 2) {
-            ma = pk_max(ma, xh[i]);
-            mb = pk_max(mb, xh[i + 1]);
-        }
-        ma = pk_max(ma, mb);
-        const float m = quad_max(fmaxf((float)ma[0], (float)ma[1]));
         const float L = 1.44269502162933349609375f * (pow2 ? lay.scale : 1.0f);   // exact: power-of-two factor
-        const float nmL = -m * L;
         float2v ev[kSlots16 / 2];
-        float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
+        auto exps = [&](float nmL) -> float {                           // e = 2^(x L - m L), returns the pixel's sum
+            float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < kSlots16 / 2; i += 2) {
-            ev[i] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][0], L, nmL)),
-                            __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][1], L, nmL))};
-            ev[i + 1] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][0], L, nmL)),
-                                __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][1], L, nmL))};
-            sa += ev[i];
-            sb += ev[i + 1];
+            for (int i = 0; i < kSlots16 / 2; i += 2) {
+                ev[i] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][0], L, nmL)),
+                                __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][1], L, nmL))};
+                ev[i + 1] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][0], L, nmL)),
+                                    __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][1], L, nmL))};
+                sa += ev[i];
+                sb += ev[i + 1];
+            }
+            sa += sb;
+            return quad_sum(sa[0] + sa[1]);
+        };
+        // softmax is shift-invariant: any reference m works as long as 2^((x - m) L) neither overflows nor
+        // underflows for the terms that matter.  Token 0 (the start-of-text token, usually the largest logit of
+        // a cross-attention row) is that reference: its own term is exactly 1, so the sum cannot underflow, and
+        // the row maximum (18 v_pk_max_f16 + a 4-lane reduction) is only computed when some logit exceeds it by
+        // more than ~69 (sum > 2^100: beyond that 1/sum would leave the normal f32 range, and past 88 the
+        // exponentials overflow) -- then the row is redone with the true maximum, as the reference does.
+        float tot = exps(-quad_bcast0((float)xh[0][0]) * L);
+        if (__builtin_expect(!(tot <= 0x1p100f), 0)) {                   // large, inf or NaN
+            half2v ma = xh[0], mb = xh[1];
+#pragma unroll
+            for (int i = 2; i < kSlots16 / 2; i += 2) {
+                ma = pk_max(ma, xh[i]);
+                mb = pk_max(mb, xh[i + 1]);
+            }
+            ma = pk_max(ma, mb);
+            tot = exps(-quad_max(fmaxf((float)ma[0], (float)ma[1])) * L);
         }
-        sa += sb;
-        const float inv = __builtin_amdgcn_rcpf(quad_sum(sa[0] + sa[1]));       // v_rcp_f32: 1 ulp
+        const float inv = __builtin_amdgcn_rcpf(tot);                    // v_rcp_f32: 1 ulp
 #pragma unroll
         for (int i = 0; i < kSlots16 / 2; ++i) {
             const half2v ph = cvt_pk_rne(ev[i] * inv);                    // probs.to(dtype)

@@ -107,6 +107,41 @@ def test_tap_qk_vs_oracle(shape, mode, defer):
     eng.close()
 
 
+@pytest.mark.parametrize('d', [64, 40, 80])
+def test_tap_wide_logit_spread(d):
+    """The fast softmax takes token 0's logit as its reference point and falls back to the true row maximum
+    when a logit exceeds it by more than ~69 (1/sum would go subnormal, then the exponentials overflow): rows
+    with a 36 / 72 / 96 / 192 spread above token 0, next to ordinary rows, still match the oracle."""
+    rng = np.random.default_rng(5)
+    heads, side, steps = 2, 16, 3
+    hw = side * side
+    qs, ks = [], []
+    for s in range(steps):
+        q, k = _qk(rng, 2, heads, hw, d, np.float16)
+        q = q.reshape(2, hw, heads, d)
+        k = k.reshape(2, 77, heads, d)
+        g = 64.0 / d                                              # keep q.k * scale at +-48 / +-96 for any d
+        q[:, ::3] = np.float16(2.0 * np.sqrt(g))
+        k[:, 0] = np.float16(-3.0 * np.sqrt(g))                    # token 0 far BELOW the others on those rows
+        k[:, 5] = np.float16(3.0 * np.sqrt(g))
+        q[:, 1::3, 1] *= np.float16(2.0)                           # second head: other rows get a 2x wider spread
+        q[:, 2::9] = np.float16(0.75 * np.sqrt(g))                 # spread 36: below the switch
+        q[:, 5::9] = np.float16(1.5 * np.sqrt(g))                  # spread 72: just above it, exponentials still finite
+        qs.append(np.ascontiguousarray(q.reshape(2, hw, heads * d)))
+        ks.append(np.ascontiguousarray(k.reshape(2, 77, heads * d)))
+    scale = d ** -0.5
+    want = _oracle_steps(qs, ks, heads, scale, np.float16, np.float16).astype(np.float64)
+    assert np.isfinite(want).all()
+    eng = _engine(defer_steps=2)
+    for q, k in zip(qs, ks):
+        eng.tap_qk(0, _dev(q), _dev(k), heads, scale, factor=1)
+    got = np.stack([v.float().cpu().numpy() for _, v in eng.items()]).astype(np.float64)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2.0 ** -10 * max(1.0, want.max())
+    np.testing.assert_allclose(got.sum(1), steps, atol=steps * 77 * 2.0 ** -11)
+    eng.close()
+
+
 def test_generic_and_mfma_agree(monkeypatch):
     """The baseline (any-shape) kernel and the MFMA kernel implement the same rounding points."""
     monkeypatch.setenv('DAAM_STRICT_EXP', '1')
