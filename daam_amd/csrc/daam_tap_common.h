@@ -1,5 +1,5 @@
-// Shared pieces of the two MFMA tap kernels (daam_tap_mfma.hip: any head_dim multiple of 8, operands
-// through registers; daam_tap_mfma64.hip: head_dim 64, operands through LDS DMA).
+// Shared pieces of the two MFMA tap kernels (daam_tap_mfma.hip: 32x32x16 tiles, any head_dim multiple of 8;
+// daam_tap_d64.hip: 16x16x32 tiles, head_dim <= 64).
 #pragma once
 #include "daam_types.h"
 
