@@ -10,15 +10,17 @@ synthetic fp16 Q / K already resident in HBM, the final flush, and one
 ``compute_global_heat_map`` (bicubic + clamp + mean over all keys) -> one ``[77, 64, 64]``
 global heat map.  Default workload = BASELINE.json configs[2]: SDXL-base-1.0 topology at
 1024x1024 (60 hooked layers, 1100 (layer, head) keys), 50 denoising steps, 77 tokens, CFG batch 2.
-Every tap goes through the per-layer C-ABI call the attention processor makes (``daam_tap_qk_enqueue``
-/ ``daam_tap_flush``), so the reported rate includes the host cost of that path.
+Every tap goes through the per-layer call the attention processor makes (``HeatMapEngine.tap_qk`` = the C++
+recorder, then ``daam_tap_qk_enqueue_many`` / ``daam_tap_flush`` of the C ABI when the maps are read), so the
+reported rate includes the host cost of that path.  Inputs: one distinct synthetic Q / K set per denoising step
+(nothing a later step reads is left in L2 / Infinity Cache by an earlier one).
 
 Multi-GPU: generations are independent (the reference is single-prompt by construction,
 daam/trace.py:172-173): rank r runs its own K generations; the only exchange is one RCCL
 all_gather of the final maps, inside the timed region.  ``scaling`` = weak.
 
-The one JSON line also carries ``roofline`` (tap kernel: algorithmic bytes / HIP-event time of
-back-to-back launches) and ``cpu_baseline`` (the torch port of the reference's hook path,
+The one JSON line also carries ``roofline`` (tap kernel: algorithmic bytes / HIP-event time of the launch
+as it occurs in the timed region) and ``cpu_baseline`` (the torch port of the reference's hook path,
 oracle/torch_hooks.py, timed on the host cores on a bounded sample).
 """
 from __future__ import annotations
