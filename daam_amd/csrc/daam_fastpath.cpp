@@ -16,6 +16,7 @@
 #include <ATen/core/Tensor.h>
 
 #include <climits>
+#include <exception>
 #include <cstdint>
 #include <vector>
 
@@ -134,21 +135,35 @@ PyObject* Recorder_tap(Recorder* self, PyObject* const* args, Py_ssize_t nargs, 
         if (PyErr_Occurred()) {
             PyErr_Clear();                                   // odd argument types: let Python complain
         } else if (layer >= 0 && layer < static_cast<long>(self->cache->size())) {
-            const LayerCache& c = (*self->cache)[layer];
-            const at::Tensor& q = THPVariable_Unpack(args[1]);
-            const at::Tensor& k = THPVariable_Unpack(args[2]);
-            if (c.valid && same3(q, c.q_size) && same3(k, c.k_size) &&
-                static_cast<int>(q.scalar_type()) == c.dtype && static_cast<int>(k.scalar_type()) == c.dtype &&
-                same_device(q, c) && same_device(k, c) &&
-                heads == c.heads && factor == c.factor && scale == c.scale && rl == c.round_logits &&
-                q.is_contiguous() && k.is_contiguous()) {
+            // torch accessors can throw (tensors without storage: fake / meta tensors under tracing); anything
+            // unusual goes to the Python path, which reports it properly
+            bool steady = false;
+            try {
+                const LayerCache& c = (*self->cache)[layer];
+                const at::Tensor& q = THPVariable_Unpack(args[1]);
+                const at::Tensor& k = THPVariable_Unpack(args[2]);
+                steady = c.valid && same3(q, c.q_size) && same3(k, c.k_size) &&
+                         static_cast<int>(q.scalar_type()) == c.dtype && static_cast<int>(k.scalar_type()) == c.dtype &&
+                         same_device(q, c) && same_device(k, c) &&
+                         heads == c.heads && factor == c.factor && scale == c.scale && rl == c.round_logits &&
+                         q.is_contiguous() && k.is_contiguous() && q.has_storage() && k.has_storage();
+            } catch (...) {
+                steady = false;
+            }
+            if (steady) {
                 if (!self->flush_cb || !self->touch_cb) { PyErr_SetString(PyExc_RuntimeError, "recorder is closed"); return nullptr; }
                 if (must_launch(self, layer)) {
                     PyObject* r = PyObject_CallNoArgs(self->flush_cb);     // launches, then calls drop()
                     if (!r) return nullptr;
                     Py_DECREF(r);
                 }
-                push(self, static_cast<int>(layer), q, k, c.desc);
+                try {
+                    push(self, static_cast<int>(layer), THPVariable_Unpack(args[1]), THPVariable_Unpack(args[2]),
+                         (*self->cache)[layer].desc);
+                } catch (const std::exception& e) {
+                    PyErr_SetString(PyExc_RuntimeError, e.what());
+                    return nullptr;
+                }
                 if (!(*self->touched)[layer]) {
                     PyObject* r = PyObject_CallOneArg(self->touch_cb, args[0]);
                     if (!r) return nullptr;
@@ -198,7 +213,12 @@ PyObject* Recorder_record(Recorder* self, PyObject* args) {
         PyErr_SetString(PyExc_ValueError, "record: bad layer or tensors");
         return nullptr;
     }
-    push(self, layer, THPVariable_Unpack(qo), THPVariable_Unpack(ko), desc);
+    try {
+        push(self, layer, THPVariable_Unpack(qo), THPVariable_Unpack(ko), desc);
+    } catch (const std::exception& e) {
+        PyErr_SetString(PyExc_RuntimeError, e.what());
+        return nullptr;
+    }
     Py_RETURN_NONE;
 }
 
