@@ -1,44 +1,52 @@
-"""Hooking framework + cross-attention locator, same behaviour and names as the reference's
-``daam/hook.py`` (ObjectHooker :22-73, AggregateHooker :76-86, UNetCrossAttentionLocator
-:89-127).  Pure host logic; duck-typed so that neither diffusers nor a GPU is needed to
-import it."""
+"""Attribute patching with guaranteed restore, and the cross-attention locator.
+
+Public names and behaviour follow the reference's ``daam/hook.py`` (``ObjectHooker`` :22-73,
+``AggregateHooker`` :76-86, ``UNetCrossAttentionLocator`` :89-127) because ``daam_amd`` is a drop-in:
+``hook()`` / ``unhook()`` raise ``RuntimeError`` on misuse, ``monkey_patch`` binds the replacement to the
+patched object, the locator defines ``layer_idx``.  The implementation is a small journal of
+``(attribute, original value)`` records that is replayed backwards on ``unhook()``.
+Pure host logic, duck-typed: neither diffusers nor a GPU is needed to import it.
+"""
 from __future__ import annotations
 
 import functools
-from typing import Any, Generic, Iterable, List, Optional, TypeVar
+from typing import Any, Callable, Dict, Generic, Iterable, Iterator, List, Optional, Tuple, TypeVar
 
 __all__ = ['ObjectHooker', 'ModuleLocator', 'AggregateHooker', 'UNetCrossAttentionLocator']
 
 T = TypeVar('T')
 
+_KEY = 'old_fn_{}'          # key format of ``old_state`` (kept for code that pokes at it like the reference's)
+
 
 class ModuleLocator(Generic[T]):
+    """Finds the objects of a model that a hooker should be attached to."""
+
     def locate(self, model) -> List[T]:
         raise NotImplementedError
 
 
 class ObjectHooker(Generic[T]):
-    """Context manager that patches attributes of ``module`` on ``hook()`` and restores them
-    on ``unhook()``.  Saved originals live in ``old_state`` under ``old_fn_<name>``."""
+    """Reversible patching of one object (``self.module``).
 
-    _PREFIX = 'old_fn_'
+    Subclasses patch in ``_hook_impl`` (usually through ``monkey_patch``) and may undo extra state in
+    ``_unhook_impl``.  Usable as a context manager."""
 
     def __init__(self, module: T):
         self.module: T = module
-        self.hooked = False
-        self.old_state = {}
+        self.hooked: bool = False
+        self._journal: List[Tuple[str, Any]] = []      # (attribute name, value before the patch), in patch order
 
-    def __enter__(self):
-        self.hook()
-        return self
+    # -- reference-compatible view of the journal ------------------------------------------------
+    @property
+    def old_state(self) -> Dict[str, Any]:
+        return {_KEY.format(name): value for name, value in self._journal}
 
-    def __exit__(self, exc_type, exc_val, exc_tb):
-        self.unhook()
-
+    # -- lifecycle -------------------------------------------------------------------------------
     def hook(self):
         if self.hooked:
             raise RuntimeError('Already hooked module')
-        self.old_state = {}
+        self._journal = []
         self.hooked = True
         self._hook_impl()
         return self
@@ -46,72 +54,89 @@ class ObjectHooker(Generic[T]):
     def unhook(self):
         if not self.hooked:
             raise RuntimeError('Module is not hooked')
-        for name, original in self.old_state.items():
-            if name.startswith(self._PREFIX):
-                setattr(self.module, name[len(self._PREFIX):], original)
+        while self._journal:
+            name, value = self._journal.pop()
+            setattr(self.module, name, value)
         self.hooked = False
         self._unhook_impl()
         return self
 
-    def monkey_patch(self, fn_name: str, fn, strict: bool = True):
-        """Replace ``module.fn_name`` by ``fn`` bound to the module as first argument.  With
-        ``strict=False`` a missing attribute is ignored (SDXL has no ``run_safety_checker``)."""
-        try:
-            original = getattr(self.module, fn_name)
-        except AttributeError:
+    def __enter__(self):
+        return self.hook()
+
+    def __exit__(self, *exc_info):
+        self.unhook()
+
+    # -- patching --------------------------------------------------------------------------------
+    def monkey_patch(self, fn_name: str, fn: Callable, strict: bool = True) -> None:
+        """``module.fn_name = partial(fn, module)``, remembering what was there.  A missing attribute is an
+        ``AttributeError`` unless ``strict=False`` (SDXL pipelines have no ``run_safety_checker``)."""
+        if not hasattr(self.module, fn_name):
             if strict:
-                raise
+                raise AttributeError(f'{type(self.module).__name__!r} object has no attribute {fn_name!r}')
             return
-        self.old_state[self._PREFIX + fn_name] = original
+        self._journal.append((fn_name, getattr(self.module, fn_name)))
         setattr(self.module, fn_name, functools.partial(fn, self.module))
 
     def monkey_super(self, fn_name: str, *args, **kwargs):
-        return self.old_state[self._PREFIX + fn_name](*args, **kwargs)
+        """Call what ``fn_name`` was before this hooker patched it."""
+        for name, value in reversed(self._journal):
+            if name == fn_name:
+                return value(*args, **kwargs)
+        raise KeyError(_KEY.format(fn_name))
 
-    def _hook_impl(self):
+    def _hook_impl(self) -> None:
         raise NotImplementedError
 
-    def _unhook_impl(self):
+    def _unhook_impl(self) -> None:
         pass
 
 
 class AggregateHooker(ObjectHooker[List[ObjectHooker]]):
-    def _hook_impl(self):
-        for hooker in self.module:
-            hooker.hook()
+    """A hooker over a list of hookers: hooks / unhooks them in list order."""
 
-    def _unhook_impl(self):
-        for hooker in self.module:
-            hooker.unhook()
-
-    def register_hook(self, hook: ObjectHooker):
+    def register_hook(self, hook: ObjectHooker) -> None:
         self.module.append(hook)
+
+    def _hook_impl(self) -> None:
+        for member in self.module:
+            member.hook()
+
+    def _unhook_impl(self) -> None:
+        for member in self.module:
+            member.unhook()
 
 
 class UNetCrossAttentionLocator(ModuleLocator[Any]):
-    """Enumerates ``transformer_block.attn2`` of every block whose class name contains
-    ``'CrossAttn'``, visiting ``up_blocks``, then ``down_blocks``, then (optionally) the mid
-    block; the position in the returned list is the ``layer_idx`` of the heat-map keys
-    (reference hook.py:95-127, trace.py:45,50).  ``restrict`` keeps only these positions
-    inside each block; names restart per block (``'{up|down|mid}-attn-{i}'``)."""
+    """Enumerates ``transformer_block.attn2`` of every block whose class name contains ``'CrossAttn'``:
+    ``up_blocks`` first, then ``down_blocks``, then (optionally) the mid block.  The position in the
+    returned list is the ``layer_idx`` of the heat-map keys (reference hook.py:95-127, trace.py:45,50).
+    ``restrict`` keeps only those positions inside each block; names restart per block
+    (``'{up|down|mid}-attn-{i}'``, so they are not unique across blocks -- reference hook.py:123)."""
 
     def __init__(self, restrict: Optional[Iterable[int]] = None, locate_middle_block: bool = False):
         self.restrict = restrict
-        self.layer_names: List[str] = []
         self.locate_middle_block = locate_middle_block
+        self.layer_names: List[str] = []
+
+    def _stages(self, unet) -> Iterator[Tuple[str, Any]]:
+        yield from (('up', block) for block in unet.up_blocks)
+        yield from (('down', block) for block in unet.down_blocks)
+        if self.locate_middle_block:
+            yield 'mid', unet.mid_block
+
+    def _wanted(self, position: int) -> bool:
+        return self.restrict is None or position in self.restrict
 
     def locate(self, model) -> List[Any]:
         self.layer_names.clear()
-        stages = [(blk, 'up') for blk in model.up_blocks] + [(blk, 'down') for blk in model.down_blocks]
-        if self.locate_middle_block:
-            stages.append((model.mid_block, 'mid'))
-        found: List[Any] = []
-        for block, tag in stages:
+        located: List[Any] = []
+        for tag, block in self._stages(model):
             if 'CrossAttn' not in type(block).__name__:
                 continue
-            attns = [tb.attn2 for st in block.attentions for tb in st.transformer_blocks]
-            kept = [a for pos, a in enumerate(attns) if self.restrict is None or pos in self.restrict]
-            found.extend(kept)
-            self.layer_names.extend(f'{tag}-attn-{i}' for i in range(len(kept))
-                                    if self.restrict is None or i in self.restrict)
-        return found
+            cross = [tb.attn2 for transformer in block.attentions for tb in transformer.transformer_blocks]
+            kept = [attn for position, attn in enumerate(cross) if self._wanted(position)]
+            located += kept
+            # the reference numbers the names over the KEPT list but filters them with `restrict` again
+            self.layer_names += [f'{tag}-attn-{i}' for i in range(len(kept)) if self._wanted(i)]
+        return located

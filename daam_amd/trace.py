@@ -131,129 +131,88 @@ class DiffusionHeatMapHooker(AggregateHooker):
         return GlobalHeatMap(self.pipe.tokenizer, prompt, maps)
 
 
-class ImageProcessorHooker(ObjectHooker):
-    """trace.py:135-147 (SDXL: remember the first post-processed image)."""
+class _CallInterceptor(ObjectHooker):
+    """Wraps methods of one pipeline-side object.  ``WRAPS`` lists ``(attribute, handler name, strict)``;
+    a handler receives the patched object first and reaches the original through ``self.monkey_super``."""
 
-    def __init__(self, processor, parent_trace: 'trace'):
-        super().__init__(processor)
+    WRAPS = ()
+
+    def __init__(self, target, parent_trace: 'trace'):
+        super().__init__(target)
         self.parent_trace = parent_trace
 
-    def _hooked_postprocess(hk_self, _processor, *args, **kwargs):
-        images = hk_self.monkey_super('postprocess', *args, **kwargs)
-        hk_self.parent_trace.last_image = images[0]
+    def _hook_impl(self):
+        for attribute, handler, strict in self.WRAPS:
+            self.monkey_patch(attribute, getattr(self, handler), strict=strict)
+
+
+class ImageProcessorHooker(_CallInterceptor):
+    """SDXL pipelines post-process through ``pipe.image_processor``: remember the first image it returns
+    (reference trace.py:135-147)."""
+
+    WRAPS = (('postprocess', '_after_postprocess', True),)
+
+    def _after_postprocess(self, _processor, *args, **kwargs):
+        images = self.monkey_super('postprocess', *args, **kwargs)
+        self.parent_trace.last_image = images[0]
         return images
 
-    def _hook_impl(self):
-        self.monkey_patch('postprocess', self._hooked_postprocess)
 
+class PipelineHooker(_CallInterceptor):
+    """What a ``pipe(prompt)`` call means for the trace (reference trace.py:150-186): exactly one prompt, the
+    running sums start from zero, the prompt and the generated image are remembered."""
 
-class PipelineHooker(ObjectHooker):
-    """trace.py:150-186: single-prompt guard, reset of the running sums at every ``pipe()``
-    call, bookkeeping of the last prompt / image."""
+    WRAPS = (('run_safety_checker', '_after_safety_checker', False),      # absent in SDXL pipelines
+             ('check_inputs', '_before_generation', True))
 
     def __init__(self, pipeline, parent_trace: 'trace'):
-        super().__init__(pipeline)
+        super().__init__(pipeline, parent_trace)
         self.heat_maps = parent_trace.all_heat_maps
-        self.parent_trace = parent_trace
 
-    def _hooked_run_safety_checker(hk_self, pipe, image, *args, **kwargs):
-        image, has_nsfw = hk_self.monkey_super('run_safety_checker', image, *args, **kwargs)
-        if getattr(pipe, 'image_processor', None):
-            if torch.is_tensor(image):
-                images = pipe.image_processor.postprocess(image, output_type='pil')
-            else:
-                images = pipe.image_processor.numpy_to_pil(image)
-        else:
-            images = pipe.numpy_to_pil(image)
-        hk_self.parent_trace.last_image = images[len(images) - 1]
-        return image, has_nsfw
-
-    def _hooked_check_inputs(hk_self, _pipe, prompt: Union[str, List[str]], *args, **kwargs):
-        if not isinstance(prompt, str) and len(prompt) > 1:
+    def _before_generation(self, _pipe, prompt: Union[str, List[str]], *args, **kwargs):
+        single = isinstance(prompt, str)
+        if not single and len(prompt) > 1:
             raise ValueError('Only single prompt generation is supported for heat map computation.')
-        last_prompt = prompt if isinstance(prompt, str) else prompt[0]
-        hk_self.heat_maps.clear()
-        hk_self.parent_trace.last_prompt = last_prompt
-        return hk_self.monkey_super('check_inputs', prompt, *args, **kwargs)
+        self.heat_maps.clear()                                             # RawHeatMapCollection.clear -> daam_reset
+        self.parent_trace.last_prompt = prompt if single else prompt[0]
+        return self.monkey_super('check_inputs', prompt, *args, **kwargs)
 
-    def _hook_impl(self):
-        self.monkey_patch('run_safety_checker', self._hooked_run_safety_checker, strict=False)  # absent in SDXL
-        self.monkey_patch('check_inputs', self._hooked_check_inputs)
+    def _after_safety_checker(self, pipe, image, *args, **kwargs):
+        checked = self.monkey_super('run_safety_checker', image, *args, **kwargs)
+        processor = getattr(pipe, 'image_processor', None)
+        if not processor:
+            pils = pipe.numpy_to_pil(checked[0])
+        elif torch.is_tensor(checked[0]):
+            pils = processor.postprocess(checked[0], output_type='pil')
+        else:
+            pils = processor.numpy_to_pil(checked[0])
+        self.parent_trace.last_image = pils[-1]
+        return checked
 
 
 class UNetCrossAttentionHooker(ObjectHooker):
-    """The attention processor installed on every located ``attn2`` (diffusers
-    attention-processor protocol, reference trace.py:252-311)."""
+    """The attention processor installed on every located ``attn2`` (diffusers attention-processor protocol;
+    replaces the reference's processor, trace.py:252-311).
+
+    Default route: the model's output comes from fused SDPA and the heat-map tap gets the projected Q / K
+    (``HeatMapEngine.tap_qk`` -- nothing ``[BH, hw, 77]``-sized is ever materialised).  Materialised route
+    (``get_attention_scores`` -> ``tap_probs`` -> ``bmm``) for attention masks, ``upcast_softmax``,
+    ``save_heads`` / ``load_heads`` and ``tap='probs'``."""
 
     def __init__(self, module, parent_trace: 'trace', context_size: int = 77, layer_idx: int = 0,
                  latent_hw: int = 9216, load_heads: bool = False, save_heads: bool = False,
                  data_dir: Union[str, Path, None] = None):
         super().__init__(module)
-        self.heat_maps = parent_trace.all_heat_maps
-        self.context_size = context_size
-        self.layer_idx = layer_idx
-        self.latent_hw = latent_hw
-        self.load_heads = load_heads
-        self.save_heads = save_heads
         self.trace = parent_trace
-        self.data_dir = Path(data_dir) if data_dir is not None else cache_dir() / 'heads'
-        self.data_dir.mkdir(parents=True, exist_ok=True)                       # trace.py:217
+        self.heat_maps = parent_trace.all_heat_maps
+        self.layer_idx = layer_idx
+        self.context_size = context_size
+        self.latent_hw = latent_hw
+        self.save_heads, self.load_heads = save_heads, load_heads
+        self.data_dir = cache_dir() / 'heads' if data_dir is None else Path(data_dir)
+        self.data_dir.mkdir(parents=True, exist_ok=True)                   # the reference creates it eagerly too (:217)
 
-    def _save_attn(self, attn_slice: torch.Tensor):
-        torch.save(attn_slice, self.data_dir / f'{self.trace._gen_idx}.pt')
-
-    def _load_attn(self) -> torch.Tensor:
-        return torch.load(self.data_dir / f'{self.trace._gen_idx}.pt')
-
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, **_ignored):
-        batch_size, sequence_length, _ = hidden_states.shape
-        attention_mask = attn.prepare_attention_mask(attention_mask, sequence_length, batch_size)
-        query = attn.to_q(hidden_states)
-        if encoder_hidden_states is None:
-            encoder_hidden_states = hidden_states
-        elif attn.norm_cross is not None:
-            encoder_hidden_states = attn.norm_cross(encoder_hidden_states)
-        key = attn.to_k(encoder_hidden_states)
-        value = attn.to_v(encoder_hidden_states)
-
-        engine = self.trace.engine
-        factor = int(math.sqrt(self.latent_hw // sequence_length))             # trace.py:285
-        tapped = key.shape[1] == self.context_size and factor != 8             # trace.py:289
-        fused = (self.trace.tap_mode == 'qk' and attention_mask is None and not self.save_heads
-                 and not self.load_heads and not getattr(attn, 'upcast_softmax', False))
-
-        if fused:
-            self.trace._gen_idx += 1
-            if tapped:
-                engine.tap_qk(self.layer_idx, query, key, attn.heads, attn.scale, factor,
-                              round_logits=not getattr(attn, 'upcast_attention', False))
-            heads = attn.heads
-            d = query.shape[-1] // heads
-            q4 = query.view(batch_size, -1, heads, d).transpose(1, 2)
-            k4 = key.view(batch_size, -1, heads, d).transpose(1, 2)
-            v4 = value.view(batch_size, -1, heads, d).transpose(1, 2)
-            out = F.scaled_dot_product_attention(q4, k4, v4, scale=attn.scale)
-            hidden_states = out.transpose(1, 2).reshape(batch_size, -1, heads * d)
-        else:
-            query = attn.head_to_batch_dim(query)
-            key = attn.head_to_batch_dim(key)
-            value = attn.head_to_batch_dim(value)
-            attention_probs = attn.get_attention_scores(query, key, attention_mask)
-            if self.save_heads:
-                self._save_attn(attention_probs)
-            elif self.load_heads:
-                attention_probs = self._load_attn()
-            factor = int(math.sqrt(self.latent_hw // attention_probs.shape[1]))
-            self.trace._gen_idx += 1
-            if attention_probs.shape[-1] == self.context_size and factor != 8:
-                engine.tap_probs(self.layer_idx, attention_probs, factor)
-            hidden_states = torch.bmm(attention_probs, value)
-            hidden_states = attn.batch_to_head_dim(hidden_states)
-
-        hidden_states = attn.to_out[0](hidden_states)      # linear proj
-        hidden_states = attn.to_out[1](hidden_states)      # dropout
-        return hidden_states
-
+    # -- installation ----------------------------------------------------------------------------
     def _hook_impl(self):
         self.original_processor = self.module.processor
         self.module.set_processor(self)
@@ -264,6 +223,65 @@ class UNetCrossAttentionHooker(ObjectHooker):
     @property
     def num_heat_maps(self):
         return len(self.heat_maps)
+
+    # -- heads cache (one file per processor call of the generation, reference :246-250) --------------
+    def _heads_file(self) -> Path:
+        return self.data_dir / f'{self.trace._gen_idx}.pt'
+
+    def _save_attn(self, attn_slice: torch.Tensor):
+        torch.save(attn_slice, self._heads_file())
+
+    def _load_attn(self) -> torch.Tensor:
+        return torch.load(self._heads_file())
+
+    # -- the processor call ------------------------------------------------------------------------
+    def _factor(self, positions: int) -> int:
+        return int(math.sqrt(self.latent_hw // positions))                 # trace.py:285
+
+    def _is_tapped(self, tokens: int, factor: int) -> bool:
+        return tokens == self.context_size and factor != 8                 # trace.py:289
+
+    def _can_fuse(self, attn, attention_mask) -> bool:
+        return (self.trace.tap_mode == 'qk' and attention_mask is None and not self.save_heads
+                and not self.load_heads and not getattr(attn, 'upcast_softmax', False))
+
+    def _fused(self, attn, query, key, value):
+        batch, positions, channels = query.shape
+        self.trace._gen_idx += 1
+        factor = self._factor(positions)
+        if self._is_tapped(key.shape[1], factor):
+            self.trace.engine.tap_qk(self.layer_idx, query, key, attn.heads, attn.scale, factor,
+                                     round_logits=not getattr(attn, 'upcast_attention', False))
+        head_dim = channels // attn.heads
+        q, k, v = (t.view(batch, -1, attn.heads, head_dim).transpose(1, 2) for t in (query, key, value))
+        out = F.scaled_dot_product_attention(q, k, v, scale=attn.scale)
+        return out.transpose(1, 2).reshape(batch, -1, channels)
+
+    def _materialised(self, attn, query, key, value, attention_mask):
+        query, key, value = (attn.head_to_batch_dim(t) for t in (query, key, value))
+        probs = attn.get_attention_scores(query, key, attention_mask)
+        if self.save_heads:
+            self._save_attn(probs)
+        elif self.load_heads:
+            probs = self._load_attn()
+        self.trace._gen_idx += 1
+        factor = self._factor(probs.shape[1])
+        if self._is_tapped(probs.shape[-1], factor):
+            self.trace.engine.tap_probs(self.layer_idx, probs, factor)
+        return attn.batch_to_head_dim(torch.bmm(probs, value))
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, **_ignored):
+        batch, positions, _ = hidden_states.shape
+        attention_mask = attn.prepare_attention_mask(attention_mask, positions, batch)
+        context = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        if encoder_hidden_states is not None and attn.norm_cross is not None:
+            context = attn.norm_cross(context)
+        query, key, value = attn.to_q(hidden_states), attn.to_k(context), attn.to_v(context)
+        if self._can_fuse(attn, attention_mask):
+            mixed = self._fused(attn, query, key, value)
+        else:
+            mixed = self._materialised(attn, query, key, value, attention_mask)
+        return attn.to_out[1](attn.to_out[0](mixed))                       # output projection, dropout
 
 
 trace: Type[DiffusionHeatMapHooker] = DiffusionHeatMapHooker

@@ -1,75 +1,90 @@
-"""Host utilities on / next to the hot path (reference ``daam/utils.py``): autocast policy,
-seeding, device choice, cache dir, token merge indices.  No spaCy / matplotlib here."""
+"""Host helpers next to the extraction path, with the names and behaviour of the reference's
+``daam/utils.py`` (device / autocast policy :22-36, seeding :46-55, cache directory :58-70, prompt-word to
+heat-map-row mapping :73-91).  spaCy and matplotlib are not needed here (the reference's ``cached_nlp`` /
+``plot_mask_heat_map`` belong to its CLI / plotting layer)."""
 from __future__ import annotations
 
 import os
 import random
 import sys
 from pathlib import Path
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
 __all__ = ['set_seed', 'compute_token_merge_indices', 'cache_dir', 'auto_device', 'auto_autocast']
 
+_EOW = '</w>'        # CLIP BPE end-of-word marker
+
+
+def _gpu() -> bool:
+    return torch.cuda.is_available()
+
 
 def auto_device(obj=torch.device('cpu')):
-    """reference utils.py:22-29."""
+    """A ``torch.device`` argument answers "which device should I use"; anything else (module, tensor) is
+    moved to the GPU when there is one."""
     if isinstance(obj, torch.device):
-        return torch.device('cuda' if torch.cuda.is_available() else 'cpu')
-    return obj.to('cuda') if torch.cuda.is_available() else obj
+        return torch.device('cuda') if _gpu() else torch.device('cpu')
+    return obj.to('cuda') if _gpu() else obj
 
 
 def auto_autocast(*args, **kwargs):
-    """reference utils.py:32-36: autocast, force-disabled without a GPU."""
-    if not torch.cuda.is_available():
-        kwargs['enabled'] = False
+    """``torch.autocast('cuda', ...)`` that is a no-op on a machine without a GPU.  On the GPU it is what puts
+    the reference's bicubic resize on the fp32 policy; the kernels here hard-wire that."""
+    if not _gpu():
+        kwargs = dict(kwargs, enabled=False)
     return torch.autocast('cuda', *args, **kwargs)
 
 
 def set_seed(seed: int) -> torch.Generator:
-    """reference utils.py:46-55."""
-    random.seed(seed)
-    np.random.seed(seed)
-    torch.manual_seed(seed)
-    if torch.cuda.is_available():
+    """Seed python / numpy / torch (all devices) and hand back a seeded generator on the default device --
+    the object the reference passes as ``generator=`` to the pipeline."""
+    for seeder in (random.seed, np.random.seed, torch.manual_seed):
+        seeder(seed)
+    if _gpu():
         torch.cuda.manual_seed_all(seed)
-    gen = torch.Generator(device=auto_device())
-    gen.manual_seed(seed)
-    return gen
+    return torch.Generator(device=auto_device()).manual_seed(seed)
 
 
 def cache_dir() -> Path:
-    """reference utils.py:58-70."""
-    if os.name == 'posix' and sys.platform != 'darwin':
-        return Path(os.environ.get('XDG_CACHE_HOME', os.path.expanduser('~/.cache')), 'daam')
+    """Per-user cache directory ``.../daam`` (XDG on Linux / BSD, ``~/Library/Caches`` on macOS,
+    ``%LOCALAPPDATA%`` on Windows) -- where ``save_heads`` / ``load_heads`` keep their files by default."""
+    home = Path(os.path.expanduser('~'))
     if sys.platform == 'darwin':
-        return Path(os.path.expanduser('~'), 'Library/Caches/daam')
-    local = os.environ.get('LOCALAPPDATA') or os.path.expanduser('~\\AppData\\Local')
-    return Path(local, 'daam')
+        base = home / 'Library' / 'Caches'
+    elif os.name == 'posix':
+        base = Path(os.environ.get('XDG_CACHE_HOME') or home / '.cache')
+    else:
+        base = Path(os.environ.get('LOCALAPPDATA') or home / 'AppData' / 'Local')
+    return base / 'daam'
+
+
+def _bare_tokens(tokenizer, text: str) -> List[str]:
+    return [piece.replace(_EOW, '') for piece in tokenizer.tokenize(text)]
+
+
+def _occurrences(haystack: Sequence[str], needle: Sequence[str]) -> List[int]:
+    n = len(needle)
+    return [i for i in range(len(haystack)) if list(haystack[i:i + n]) == list(needle)]
 
 
 def compute_token_merge_indices(tokenizer, prompt: str, word: str, word_idx: Optional[int] = None,
                                 offset_idx: int = 0) -> Tuple[List[int], Optional[int]]:
-    """Rows of the global heat map that belong to ``word`` (reference utils.py:73-91):
-    lower-case, strip the ``</w>`` end-of-word marker, match the word's token sequence at
-    every position of the prompt, and shift by one for the SOS row.  ``word_idx`` bypasses the
-    search.  Raises ``ValueError`` when the word does not occur."""
+    """Rows of a global heat map that belong to ``word``.
+
+    Row 0 is the start-of-text token, so prompt token ``i`` lives in row ``i + 1``.  The word is matched as a
+    token sequence (case-folded, end-of-word markers stripped) at every position of the prompt; every
+    occurrence contributes all of its sub-word rows, shifted by ``offset_idx``.  ``word_idx`` names the prompt
+    token directly and skips the search.  A word that does not occur is a ``ValueError`` (same message as the
+    reference)."""
     if word_idx is not None:
         return [word_idx + 1], word_idx
-
-    def pieces(text: str) -> List[str]:
-        return [tok.replace('</w>', '') for tok in tokenizer.tokenize(text)]
-
-    prompt_toks = pieces(prompt.lower())
     word = word.lower()
-    word_toks = pieces(word)
-    n = len(word_toks)
-    rows: List[int] = []
-    for start in range(len(prompt_toks)):
-        if prompt_toks[start:start + n] == word_toks:
-            rows.extend(start + offset_idx + j for j in range(n))
+    needle = _bare_tokens(tokenizer, word)
+    starts = _occurrences(_bare_tokens(tokenizer, prompt.lower()), needle)
+    rows = [start + offset_idx + j + 1 for start in starts for j in range(len(needle))]
     if not rows:
         raise ValueError(f'Search word {word} not found in prompt!')
-    return [r + 1 for r in rows], word_idx
+    return rows, word_idx
