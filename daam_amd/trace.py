@@ -211,11 +211,19 @@ class UNetCrossAttentionHooker(ObjectHooker):
         self.save_heads, self.load_heads = save_heads, load_heads
         self.data_dir = cache_dir() / 'heads' if data_dir is None else Path(data_dir)
         self.data_dir.mkdir(parents=True, exist_ok=True)                   # the reference creates it eagerly too (:217)
+        self._factors = {}                                                 # positions -> factor
 
     # -- installation ----------------------------------------------------------------------------
     def _hook_impl(self):
-        self.original_processor = self.module.processor
-        self.module.set_processor(self)
+        attn = self.module
+        self.original_processor = attn.processor
+        # per-generation constants of the default route
+        self._heads, self._scale = attn.heads, attn.scale
+        self._round_logits = not getattr(attn, 'upcast_attention', False)
+        self._fusable = (self.trace.tap_mode == 'qk' and not self.save_heads and not self.load_heads
+                         and not getattr(attn, 'upcast_softmax', False))
+        self._tap_qk = self.trace.engine.tap_qk           # the C++ recorder's entry point on a deferred trace
+        attn.set_processor(self)
 
     def _unhook_impl(self):
         self.module.set_processor(self.original_processor)
@@ -236,29 +244,33 @@ class UNetCrossAttentionHooker(ObjectHooker):
 
     # -- the processor call ------------------------------------------------------------------------
     def _factor(self, positions: int) -> int:
-        return int(math.sqrt(self.latent_hw // positions))                 # trace.py:285
+        factor = self._factors.get(positions)
+        if factor is None:
+            factor = self._factors[positions] = int(math.sqrt(self.latent_hw // positions))   # trace.py:285
+        return factor
 
     def _is_tapped(self, tokens: int, factor: int) -> bool:
         return tokens == self.context_size and factor != 8                 # trace.py:289
 
-    def _can_fuse(self, attn, attention_mask) -> bool:
-        return (self.trace.tap_mode == 'qk' and attention_mask is None and not self.save_heads
-                and not self.load_heads and not getattr(attn, 'upcast_softmax', False))
-
-    def _fused(self, attn, query, key, value):
-        batch, positions, channels = query.shape
+    def _fused(self, attn, hidden_states, context):
+        """Default route.  Runs 60-70 times per denoising step: the attribute lookups that cannot change during
+        a generation (heads, scale, the engine's recorder entry point) are resolved once in ``_hook_impl``."""
+        query, key, value = attn.to_q(hidden_states), attn.to_k(context), attn.to_v(context)
         self.trace._gen_idx += 1
+        batch, positions, channels = query.shape
         factor = self._factor(positions)
-        if self._is_tapped(key.shape[1], factor):
-            self.trace.engine.tap_qk(self.layer_idx, query, key, attn.heads, attn.scale, factor,
-                                     round_logits=not getattr(attn, 'upcast_attention', False))
-        head_dim = channels // attn.heads
-        q, k, v = (t.view(batch, -1, attn.heads, head_dim).transpose(1, 2) for t in (query, key, value))
-        out = F.scaled_dot_product_attention(q, k, v, scale=attn.scale)
+        if factor != 8 and key.shape[1] == self.context_size:
+            self._tap_qk(self.layer_idx, query, key, self._heads, self._scale, factor, self._round_logits)
+        heads = self._heads
+        head_dim = channels // heads
+        out = F.scaled_dot_product_attention(query.view(batch, -1, heads, head_dim).transpose(1, 2),
+                                             key.view(batch, -1, heads, head_dim).transpose(1, 2),
+                                             value.view(batch, -1, heads, head_dim).transpose(1, 2), scale=self._scale)
         return out.transpose(1, 2).reshape(batch, -1, channels)
 
-    def _materialised(self, attn, query, key, value, attention_mask):
-        query, key, value = (attn.head_to_batch_dim(t) for t in (query, key, value))
+    def _materialised(self, attn, hidden_states, context, attention_mask):
+        query, key, value = (attn.head_to_batch_dim(t)
+                             for t in (attn.to_q(hidden_states), attn.to_k(context), attn.to_v(context)))
         probs = attn.get_attention_scores(query, key, attention_mask)
         if self.save_heads:
             self._save_attn(probs)
@@ -271,16 +283,18 @@ class UNetCrossAttentionHooker(ObjectHooker):
         return attn.batch_to_head_dim(torch.bmm(probs, value))
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, **_ignored):
-        batch, positions, _ = hidden_states.shape
-        attention_mask = attn.prepare_attention_mask(attention_mask, positions, batch)
-        context = hidden_states if encoder_hidden_states is None else encoder_hidden_states
-        if encoder_hidden_states is not None and attn.norm_cross is not None:
-            context = attn.norm_cross(context)
-        query, key, value = attn.to_q(hidden_states), attn.to_k(context), attn.to_v(context)
-        if self._can_fuse(attn, attention_mask):
-            mixed = self._fused(attn, query, key, value)
+        if encoder_hidden_states is None:
+            context = hidden_states
+        elif attn.norm_cross is None:
+            context = encoder_hidden_states
         else:
-            mixed = self._materialised(attn, query, key, value, attention_mask)
+            context = attn.norm_cross(encoder_hidden_states)
+        if self._fusable and attention_mask is None:       # prepare_attention_mask(None, ...) is None: nothing to prepare
+            mixed = self._fused(attn, hidden_states, context)
+        else:
+            batch, positions, _ = hidden_states.shape
+            attention_mask = attn.prepare_attention_mask(attention_mask, positions, batch)
+            mixed = self._materialised(attn, hidden_states, context, attention_mask)
         return attn.to_out[1](attn.to_out[0](mixed))                       # output projection, dropout
 
 
