@@ -1,28 +1,48 @@
-import sys, time, cProfile, pstats, io, os
+"""Debug: where the integrated-harness overhead of tests/test_gpu_integration.py comes from (MI355X)."""
+import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import torch
 from oracle import fake_diffusers as fd
 import test_gpu_integration as T
 import daam_amd
+
 pipe = fd.make_pipe('sdxl', device='cuda:0', dtype=torch.float16, batch=2, seed=3, mini=False, identity_proj=False)
 T._resident_inputs(pipe, 4)
 mods = [s.module for s in pipe.unet.execution_order()]
-for m in mods: m.set_processor(T._SdpaProcessor())
-prompt='a photo of a monkey'
-def sync(): torch.cuda.synchronize()
-# 1. trace setup/teardown only
-for _ in range(2):
-    with daam_amd.trace(pipe) as tc: pass
-sync(); t0=time.perf_counter()
-for _ in range(5):
-    with daam_amd.trace(pipe) as tc: pass
-sync(); print('trace enter+exit (no generation): %.2f ms' % ((time.perf_counter()-t0)/5*1e3))
-# 2. generation inside one long-lived trace
-with daam_amd.trace(pipe) as tc:
-    pipe(prompt, num_inference_steps=5); tc.compute_global_heat_map(); sync()
-    t0=time.perf_counter(); pipe(prompt, num_inference_steps=20); sync(); t1=time.perf_counter()
-    tc.compute_global_heat_map(); sync(); t2=time.perf_counter()
-    print('traced 20 steps: %.3f ms/step; compute_global_heat_map (incl. tap launch): %.2f ms' % ((t1-t0)/20*1e3, (t2-t1)*1e3))
-    pr=cProfile.Profile(); pr.enable(); pipe(prompt, num_inference_steps=5); sync(); pr.disable()
-    s=io.StringIO(); pstats.Stats(pr,stream=s).sort_stats('tottime').print_stats(14); print(s.getvalue()[:2600])
-sync(); t0=time.perf_counter(); pipe(prompt, num_inference_steps=20); sync(); print('plain 20 steps: %.3f ms/step' % ((time.perf_counter()-t0)/20*1e3))
+for m in mods:
+    m.set_processor(T._SdpaProcessor())
+prompt, steps = 'a photo of a monkey', 20
+
+
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps / steps * 1e3
+
+
+plain = timed(lambda: pipe(prompt, num_inference_steps=steps))
+print(f'plain SDPA processor            {plain:7.3f} ms/step')
+
+
+def traced(noop_tap=False, finalize=True, **kw):
+    def run():
+        with daam_amd.trace(pipe, **kw) as tc:
+            if noop_tap:
+                for h in tc.module[:-2]:
+                    h._tap_qk = lambda *a: None
+            pipe(prompt, num_inference_steps=steps)
+            if finalize and not noop_tap:
+                tc.compute_global_heat_map()
+    return run
+
+
+for name, fn in [('trace, tap replaced by a no-op', traced(noop_tap=True)),
+                 ('trace, no compute_global_heat_map', traced(finalize=False)),
+                 ('trace (default)', traced()),
+                 ('trace, defer_steps=4', traced(defer_steps=4)),
+                 ('trace, defer_steps=0 (immediate)', traced(defer_steps=0))]:
+    t = timed(fn)
+    print(f'{name:38s} {t:7.3f} ms/step  (+{t - plain:.3f})')
