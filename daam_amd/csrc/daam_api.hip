@@ -22,7 +22,7 @@ bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t 
 int tap_mfma_tile_pixels();
 int tap_mfma_ksteps(int head_dim);
 int tap_mfma_max_steps();
-hipError_t launch_tap_d64(const TapLaunch&, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
+hipError_t launch_tap_d64(const TapLaunch&, int in_dtype, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
 bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                        const void* q, const void* k);
 
@@ -438,10 +438,13 @@ static void fill_layer(const DaamCtx* c, const Layer& l, const DaamQKDesc& d, in
     (void)c;
 }
 
+static bool use_d64_bf16(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k);
+
 static bool use_mfma(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
     if (c->force_generic) return false;
     if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) return false;
+    if (d.in_dtype == DAAM_BF16) return use_d64_bf16(c, d, q, k);
     return tap_mfma_supported(d.in_dtype, d.head_dim, d.tokens, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b,
                               d.q_stride_h, d.k_stride_b, d.k_stride_h);
 }
@@ -456,8 +459,18 @@ static bool use_d64(const DaamCtx* c, const DaamQKDesc& d, const void* q, const 
                                            d.k_stride_b, d.k_stride_h, q, k);
 }
 
+// bf16 pipelines: only the 16x16-tile kernel has a bf16 variant (head_dim <= 64, 77 tokens, bf16-rounded logits);
+// everything else of a bf16 pipeline runs on the any-shape kernel
+static bool use_d64_bf16(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
+{
+    return d.in_dtype == DAAM_BF16 && !c->no_d64 && c->fast_exp && d.round_logits && d.tokens == 77 && d.hw % 8 == 0 &&
+           tap_d64_supported(d.head_dim, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h, d.k_stride_b,
+                             d.k_stride_h, q, k);
+}
+
 static int mfma_kind(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
+    if (d.in_dtype == DAAM_BF16) return 66;                   // only reached when use_d64_bf16() holds
     if (use_d64(c, d, q, k)) return 65;
     return tap_mfma_ksteps(d.head_dim);
 }
@@ -480,7 +493,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     L.wgs_per_xcd = (L.total_wgs + 7) / 8;
     c->last_block[0] = 256;
     const int kd1 = mfma ? mfma_kind(c, *d, q, k) : 0;
-    hipError_t e = kd1 == 65 ? launch_tap_d64(L, c->acc_dtype, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+    hipError_t e = (kd1 == 65 || kd1 == 66) ? launch_tap_d64(L, d->in_dtype, c->acc_dtype, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                         : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
                                              &c->last_grid[0], &c->last_lds[0]);
@@ -572,7 +585,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             // every step of the layer must qualify for the specialised kernel, else the generic MFMA one
             const int want = mfma_kind(c, p.d, p.q, p.k);
             if (per[i].empty()) kind[i] = want;
-            else if (kind[i] != want) kind[i] = tap_mfma_ksteps(p.d.head_dim);
+            else if (kind[i] != want) kind[i] = p.d.in_dtype == DAAM_BF16 ? 0 : tap_mfma_ksteps(p.d.head_dim);
         }
         per[i].push_back(&p);
     }
@@ -625,7 +638,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         L.total_wgs = wg;
         L.wgs_per_xcd = (wg + 7) / 8;
         int grid = 0;
-        e = kd == 65 ? launch_tap_d64(L, c->acc_dtype, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
+        e = (kd == 65 || kd == 66) ? launch_tap_d64(L, in_dtype, c->acc_dtype, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
           : kd ? launch_tap_mfma(L, c->acc_dtype, max_d, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
                : launch_tap_generic(L, in_dtype, c->acc_dtype, max_d, s, &grid, &c->last_lds[0]);
         grid_total += grid;
@@ -713,7 +726,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             k.side = l.side;
             k.tab = l.tab;
             int cls = 3;
-            if (!c->force_generic && c->acc_dtype != DAAM_BF16) {     // bf16 planes: any-shape kernel only
+            if (!c->force_generic) {
                 if (l.tab < 0 && (l.hw % 8) == 0) cls = 0;
                 else if (l.tab >= 0 && finalize_up_supported(l.side, c->out_side)) cls = l.side == 32 ? 1 : 2;
             }

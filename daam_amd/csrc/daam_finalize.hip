@@ -43,6 +43,20 @@ template <> struct Plane<_Float16> {
         for (int i = 0; i < 8; ++i) a[i] += fmaxf((float)p[i], 0.f);
     }
 };
+typedef unsigned short ushort8 __attribute__((ext_vector_type(8)));
+template <> struct Plane<bf16_t> {                         // bf16 planes: widened by a shift
+    static constexpr int kPerPiece = 8;
+    using Piece = ushort8;
+    static __device__ __forceinline__ float f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+    static __device__ __forceinline__ void widen(const Piece& p, float* dst) {
+        *reinterpret_cast<float4v*>(dst) = float4v{f(p[0]), f(p[1]), f(p[2]), f(p[3])};
+        *reinterpret_cast<float4v*>(dst + 4) = float4v{f(p[4]), f(p[5]), f(p[6]), f(p[7])};
+    }
+    static __device__ __forceinline__ void clamp_add(const Piece& p, float* a) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += fmaxf(f(p[i]), 0.f);
+    }
+};
 template <> struct Plane<float> {
     static constexpr int kPerPiece = 4;
     using Piece = float4v;
@@ -432,12 +446,13 @@ __global__ __launch_bounds__(256) void finalize_same_kernel(const FinLaunch L)
 hipError_t launch_finalize_same(const FinLaunch& L, int acc_dtype, hipStream_t stream, int* grid_out)
 {
     const int plane = L.out_side * L.out_side;
-    const int per = acc_dtype == 0 ? 8 : 4;
+    const int per = acc_dtype == 1 ? 4 : 8;
     // waves never straddle token planes: per-token piece count rounded up to whole waves
     const int waves = L.tokens * ((plane / per + 63) / 64);
     dim3 grid((waves + 3) / 4, L.n_chunks);
     *grid_out = grid.x * grid.y;
     if (acc_dtype == 0) hipLaunchKernelGGL((finalize_same_kernel<_Float16>), grid, dim3(256), 0, stream, L);
+    else if (acc_dtype == 2) hipLaunchKernelGGL((finalize_same_kernel<bf16_t>), grid, dim3(256), 0, stream, L);
     else hipLaunchKernelGGL((finalize_same_kernel<float>), grid, dim3(256), 0, stream, L);
     return hipGetLastError();
 }
@@ -452,9 +467,11 @@ hipError_t launch_finalize_up(const FinLaunch& L, int side, int acc_dtype, int m
         hipLaunchKernelGGL(finalize_up32_mfma_kernel, grid, dim3(256), 0, stream, L);
     } else if (side == 32) {
         if (acc_dtype == 0) hipLaunchKernelGGL((finalize_up_kernel<_Float16, 32>), grid, dim3(256), 0, stream, L);
+        else if (acc_dtype == 2) hipLaunchKernelGGL((finalize_up_kernel<bf16_t, 32>), grid, dim3(256), 0, stream, L);
         else hipLaunchKernelGGL((finalize_up_kernel<float, 32>), grid, dim3(256), 0, stream, L);
     } else {
         if (acc_dtype == 0) hipLaunchKernelGGL((finalize_up_kernel<_Float16, 16>), grid, dim3(256), 0, stream, L);
+        else if (acc_dtype == 2) hipLaunchKernelGGL((finalize_up_kernel<bf16_t, 16>), grid, dim3(256), 0, stream, L);
         else hipLaunchKernelGGL((finalize_up_kernel<float, 16>), grid, dim3(256), 0, stream, L);
     }
     return hipGetLastError();

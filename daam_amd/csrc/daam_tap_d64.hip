@@ -64,6 +64,90 @@ __device__ __forceinline__ float quad_sum(float v) {
 template <typename ACC_T> struct Pair;
 template <> struct Pair<_Float16> { using T = half2v; };
 template <> struct Pair<float> { using T = float2v; };
+template <> struct Pair<bf16_t> { using T = float2v; };      // bf16 sums live in registers as f32 holding bf16 values
+template <> struct AccVec<bf16_t> { static constexpr int kPerVec = 8; };
+
+// running-sum element <-> its register representation
+template <typename ACC_T> __device__ __forceinline__ auto from_acc(ACC_T v) { return v; }
+template <> __device__ __forceinline__ auto from_acc<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+template <typename ACC_T, typename R> __device__ __forceinline__ ACC_T to_acc(R v) { return (ACC_T)v; }
+template <> __device__ __forceinline__ bf16_t to_acc<bf16_t, float>(float v) {
+    bf16_t r;
+    r.bits = (uint16_t)(__float_as_uint(v) >> 16);            // exact: the register already holds a bf16 value
+    return r;
+}
+
+// pipeline dtype of Q / K: selects the MFMA and the softmax rounding points
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct InF16 {
+    static constexpr bool kBf16 = false;
+    static __device__ __forceinline__ floatx4 mfma(const half8& a, const half8& b, const floatx4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+struct InBF16 {                                              // operands travel as 16 raw bytes (half8 as a bit container)
+    static constexpr bool kBf16 = true;
+    static __device__ __forceinline__ floatx4 mfma(const half8& a, const half8& b, const floatx4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+// f32 pair -> nearest bf16 (ties to even, one v_cvt_pk_bf16_f32), widened back to f32
+__device__ __forceinline__ float2v round_bf16_pair(float2v v) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v[0]), "v"(v[1]));
+    return float2v{__uint_as_float(r << 16), __uint_as_float(r & 0xffff0000u)};
+}
+
+// bf16 pipeline: logits = bf16(f32(q.k) * scale) -> f32 softmax -> bf16(p) -> acc = bf16(acc + p) (or f32 acc += p).
+// Same structure as the fast fp16 path below (token 0 as the reference point, true maximum only on overflow);
+// the values stay in f32 registers, so the exponent argument is a packed f32 FMA.
+template <typename ACC_T>
+__device__ __forceinline__ void softmax20_accumulate_bf16(const floatx4 (&c)[5], const TapLayer& lay, int h,
+                                                          float2v (&run)[kSlots16 / 2])
+{
+    float2v x[kSlots16 / 2];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) {
+        x[2 * mt] = round_bf16_pair(float2v{c[mt][0], c[mt][1]} * lay.scale);
+        x[2 * mt + 1] = round_bf16_pair(float2v{c[mt][2], c[mt][3]} * lay.scale);
+    }
+    if (h == 3) {                                                       // tokens 77, 78, 79
+        const float ninf = -__builtin_inff();
+        x[8][1] = ninf;
+        x[9] = float2v{ninf, ninf};
+    }
+    const float L = 1.44269502162933349609375f;
+    float2v ev[kSlots16 / 2];
+    auto exps = [&](float nmL) -> float {
+        float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < kSlots16 / 2; i += 2) {
+            const float2v ta = __builtin_elementwise_fma(x[i], float2v{L, L}, float2v{nmL, nmL});
+            const float2v tb = __builtin_elementwise_fma(x[i + 1], float2v{L, L}, float2v{nmL, nmL});
+            ev[i] = float2v{__builtin_amdgcn_exp2f(ta[0]), __builtin_amdgcn_exp2f(ta[1])};
+            ev[i + 1] = float2v{__builtin_amdgcn_exp2f(tb[0]), __builtin_amdgcn_exp2f(tb[1])};
+            sa += ev[i];
+            sb += ev[i + 1];
+        }
+        sa += sb;
+        return quad_sum(sa[0] + sa[1]);
+    };
+    float tot = exps(-quad_bcast0(x[0][0]) * L);
+    if (__builtin_expect(!(tot <= 0x1p100f), 0)) {                       // large, inf or NaN: redo with the row maximum
+        float2v m2 = x[0];
+#pragma unroll
+        for (int i = 1; i < kSlots16 / 2; ++i) m2 = float2v{fmaxf(m2[0], x[i][0]), fmaxf(m2[1], x[i][1])};
+        tot = exps(-quad_max(fmaxf(m2[0], m2[1])) * L);
+    }
+    const float inv = __builtin_amdgcn_rcpf(tot);
+#pragma unroll
+    for (int i = 0; i < kSlots16 / 2; ++i) {
+        const float2v p = round_bf16_pair(ev[i] * inv);                   // probs.to(dtype)
+        if constexpr (sizeof(ACC_T) == 2) run[i] = round_bf16_pair(run[i] + p);   // heatmap.py:156 in bf16
+        else run[i] += p;
+    }
+}
 
 template <typename ACC_T, bool FAST_EXP>
 __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], const TapLayer& lay, int h,
@@ -168,8 +252,8 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
     }
 }
 
-template <typename ACC_T, bool FAST_EXP>
-__global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
+template <typename IN, typename ACC_T, bool FAST_EXP>
+__global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
 {
     constexpr int KCH = (kTok * 8 + 255) / 256;               // 16-B K pieces per thread per step (3)
     constexpr int VEC = AccVec<ACC_T>::kPerVec;
@@ -228,12 +312,17 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_ker
 #pragma unroll
         for (int i = 0; i < kSlots16; ++i) {
             const int t = slot16_token(i, h);
-            run0[i >> 1][i & 1] = t < kTok ? stage[t * kMfmaPixels + wave * 32 + j] : (ACC_T)0;
-            run1[i >> 1][i & 1] = t < kTok ? stage[t * kMfmaPixels + wave * 32 + 16 + j] : (ACC_T)0;
+            if (t < kTok) {
+                run0[i >> 1][i & 1] = from_acc<ACC_T>(stage[t * kMfmaPixels + wave * 32 + j]);
+                run1[i >> 1][i & 1] = from_acc<ACC_T>(stage[t * kMfmaPixels + wave * 32 + 16 + j]);
+            } else {
+                run0[i >> 1][i & 1] = 0;
+                run1[i >> 1][i & 1] = 0;
+            }
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < kSlots16; ++i) { run0[i >> 1][i & 1] = (ACC_T)0; run1[i >> 1][i & 1] = (ACC_T)0; }
+        for (int i = 0; i < kSlots16; ++i) { run0[i >> 1][i & 1] = 0; run1[i >> 1][i & 1] = 0; }
     }
     __syncthreads();                                          // staging reads done; sptr visible
     // head_dim < 64 (multiple of 8; SD-v1.5's 40): the contraction runs over 64 with zeros beyond head_dim --
@@ -305,16 +394,21 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_ker
         for (int mt = 0; mt < 5; ++mt) {
             const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kD64Row);
             const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kD64Row + 64);
-            c0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bq0[0], floatx4{0, 0, 0, 0}, 0, 0, 0);
-            c1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bq1[0], floatx4{0, 0, 0, 0}, 0, 0, 0);
-            c0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bq0[1], c0[mt], 0, 0, 0);
-            c1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bq1[1], c1[mt], 0, 0, 0);
+            c0[mt] = IN::mfma(a0, bq0[0], floatx4{0, 0, 0, 0});
+            c1[mt] = IN::mfma(a0, bq1[0], floatx4{0, 0, 0, 0});
+            c0[mt] = IN::mfma(a1, bq0[1], c0[mt]);
+            c1[mt] = IN::mfma(a1, bq1[1], c1[mt]);
         }
         const int nx = min(s + 1, n_steps - 1);               // branch-free: the last step re-fetches itself
         issue_k(nx);
         issue_q(nx);
-        softmax20_accumulate<ACC_T, FAST_EXP>(c0, lay, h, run0);
-        softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
+        if constexpr (IN::kBf16) {
+            softmax20_accumulate_bf16<ACC_T>(c0, lay, h, run0);
+            softmax20_accumulate_bf16<ACC_T>(c1, lay, h, run1);
+        } else {
+            softmax20_accumulate<ACC_T, FAST_EXP>(c0, lay, h, run0);
+            softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
+        }
         commit_k((s + 1) & 1);
     }
     __syncthreads();                                          // all K reads done before the staging tile reuses the space
@@ -324,8 +418,8 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_d64_ker
     for (int i = 0; i < kSlots16; ++i) {
         const int t = slot16_token(i, h);
         if (t < kTok) {
-            stage[t * kMfmaPixels + wave * 32 + j] = run0[i >> 1][i & 1];
-            stage[t * kMfmaPixels + wave * 32 + 16 + j] = run1[i >> 1][i & 1];
+            stage[t * kMfmaPixels + wave * 32 + j] = to_acc<ACC_T>(run0[i >> 1][i & 1]);
+            stage[t * kMfmaPixels + wave * 32 + 16 + j] = to_acc<ACC_T>(run1[i >> 1][i & 1]);
         }
     }
     __syncthreads();
@@ -348,28 +442,37 @@ bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, i
     return ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
 }
 
-template <typename ACC_T, bool FAST>
+template <typename IN, typename ACC_T, bool FAST>
 static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out)
 {
     const size_t lds = tap_d64_lds_bytes<ACC_T>();
     *lds_out = lds;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_d64_kernel<ACC_T, FAST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_d64_kernel<IN, ACC_T, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((tap_d64_kernel<ACC_T, FAST>), dim3(grid), dim3(256), lds, stream, L);
+    hipLaunchKernelGGL((tap_d64_kernel<IN, ACC_T, FAST>), dim3(grid), dim3(256), lds, stream, L);
     return hipGetLastError();
 }
 
-hipError_t launch_tap_d64(const TapLaunch& L, int acc_dtype, int fast_exp, hipStream_t stream, int* grid_out, int* lds_out)
+hipError_t launch_tap_d64(const TapLaunch& L, int in_dtype, int acc_dtype, int fast_exp, hipStream_t stream, int* grid_out, int* lds_out)
 {
     const int grid = L.wgs_per_xcd * 8;
     *grid_out = grid;
     size_t lds = 0;
     hipError_t e;
-    if (fast_exp) e = acc_dtype == 0 ? launch_d64<_Float16, true>(L, stream, grid, &lds) : launch_d64<float, true>(L, stream, grid, &lds);
-    else e = acc_dtype == 0 ? launch_d64<_Float16, false>(L, stream, grid, &lds) : launch_d64<float, false>(L, stream, grid, &lds);
+    if (in_dtype == 2) {                                       // bf16 pipeline: one softmax flavour
+        if (acc_dtype == 2) e = launch_d64<InBF16, bf16_t, true>(L, stream, grid, &lds);
+        else if (acc_dtype == 1) e = launch_d64<InBF16, float, true>(L, stream, grid, &lds);
+        else return hipErrorInvalidValue;
+    } else if (acc_dtype != 0 && acc_dtype != 1) {
+        return hipErrorInvalidValue;
+    } else if (fast_exp) {
+        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, true>(L, stream, grid, &lds) : launch_d64<InF16, float, true>(L, stream, grid, &lds);
+    } else {
+        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, false>(L, stream, grid, &lds) : launch_d64<InF16, float, false>(L, stream, grid, &lds);
+    }
     *lds_out = (int)lds;
     return e;
 }

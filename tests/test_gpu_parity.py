@@ -200,7 +200,7 @@ def test_tap_probs_bit_exact(dt):
 
 
 @pytest.mark.parametrize('sides', [(64,), (32,), (16, 32, 64), (128, 64), (8,), (24, 48)])
-@pytest.mark.parametrize('acc', ['float16', 'float32'])
+@pytest.mark.parametrize('acc', ['float16', 'float32', 'bfloat16'])
 @pytest.mark.parametrize('path', ['default', 'no_mfma', 'general'])
 def test_finalize_vs_oracle(sides, acc, path, monkeypatch):
     """bicubic (A=-0.75, border-clamped taps) -> clamp -> mean over keys, incl. the x0.5
@@ -211,12 +211,14 @@ def test_finalize_vs_oracle(sides, acc, path, monkeypatch):
     rng = np.random.default_rng(len(sides) * 31 + sides[0])
     out_side = 96 if 24 in sides else 64
     heads = 2
-    eng = _engine(n_layers=len(sides), out_side=out_side, accumulate='exact' if acc == 'float16' else 'float32')
+    eng = _engine(n_layers=len(sides), out_side=out_side, accumulate='float32' if acc == 'float32' else 'exact')
+    np_dt = ho.BF16 if acc == 'bfloat16' else acc
     raw = []
     for layer, side in enumerate(sides):
         # signed planes so that the clamp matters; feed them through the probs path (adds to zero)
-        planes = (rng.standard_normal((2 * heads, side * side, 77)) * 3).astype(acc)
-        eng.tap_probs(layer, torch.from_numpy(planes).to(DEV), factor=out_side // side if side <= out_side else 0)
+        planes = rng.standard_normal((2 * heads, side * side, 77)).astype(np.float32) * 3
+        planes = ho.round_bf16(planes) if acc == 'bfloat16' else planes.astype(acc)
+        eng.tap_probs(layer, _dev(planes, np_dt), factor=out_side // side if side <= out_side else 0)
         kept = ho.unravel(planes)
         factor = out_side // side if side <= out_side else 0
         raw += [((factor, layer, h), kept[h]) for h in range(heads)]
