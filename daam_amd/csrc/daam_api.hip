@@ -122,6 +122,11 @@ struct Ring {
     hipError_t commit(size_t off, size_t bytes, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0) {
         return launch_upload(dev + off, host_dev + off, bytes, zero, zero_bytes, s);
     }
+    hipError_t release_range(size_t begin, size_t end, hipStream_t s) {
+        cur_begin = begin;
+        cur_end = end;
+        return release(s);
+    }
     hipError_t release(hipStream_t s) {
         hipEvent_t ev;
         if (!pool.empty()) { ev = pool.back(); pool.pop_back(); }
@@ -177,6 +182,10 @@ struct DaamCtx {
     int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
     int profile = 0;
     hipEvent_t prof_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    static constexpr int kAux = 3;     // side streams of multi-kind tap flushes (see daam_tap_flush)
+    hipStream_t aux_stream[kAux] = {nullptr, nullptr, nullptr};
+    hipEvent_t aux_fork = nullptr, aux_join[kAux] = {nullptr, nullptr, nullptr};
+    int no_side_stream = 0;
 
     int force_generic = 0;
     int fast_exp = 0;
@@ -285,6 +294,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->no_mfma_finalize = nm && nm[0] == '1';
     const char* n16 = getenv("DAAM_NO_D64");            // debugging: 32x32-tile kernel also for head_dim 64
     c->no_d64 = n16 && n16[0] == '1';
+    const char* nss = getenv("DAAM_NO_SIDE_STREAM");        // debugging / A-B: every tap kernel of a flush on the caller's stream
+    c->no_side_stream = nss && nss[0] == '1';
 
     // softmax flavour of the MFMA tap: fast (default; exponent by one mixed-precision FMA, ~1e-6 relative,
     // same deviation class as the f32 summation order of q.k -- DESIGN.md section 3.1) or compensated
@@ -306,6 +317,11 @@ int daam_ctx_destroy(DaamCtx* c)
     for (auto& pair : c->prof_ev)
         for (auto& ev : pair)
             if (ev) (void)hipEventDestroy(ev);
+    if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
+    for (auto& ev : c->aux_join)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto& st : c->aux_stream)
+        if (st) (void)hipStreamDestroy(st);
     if (c->d_up32_ops) (void)hipFree(c->d_up32_ops);
     if (c->d_tab_idx) (void)hipFree(c->d_tab_idx);
     if (c->d_tab_w) (void)hipFree(c->d_tab_w);
@@ -594,7 +610,9 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         if (std::find(kinds.begin(), kinds.end(), kd) == kinds.end()) kinds.push_back(kd);
     int rc = 0;
     int grid_total = 0;
-    bool ev_started = false;
+    // pass 1: the tables of every kernel kind -> ring -> device (all on the caller's stream)
+    struct Prepared { int kd; TapLaunch L; int max_d; int all_round; size_t ring_begin, ring_end; };
+    std::vector<Prepared> prepared;
     for (int kd : kinds) {
         size_t n_layers = 0, n_ptrs = 0;
         for (size_t i = 0; i < order.size(); ++i)
@@ -628,26 +646,76 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         }
         e = c->ring.commit(off, bytes, s);
         if (e != hipSuccess) { rc = fail((int)e, "table upload: %s", hipGetErrorString(e)); break; }
-        if (c->profile && !ev_started) { (void)hipEventRecord(c->prof_ev[0][0], s); ev_started = true; }
-        TapLaunch L;
-        memset(&L, 0, sizeof L);
-        L.layers = reinterpret_cast<const TapLayer*>(c->ring.dev + off);
-        L.ptrs = reinterpret_cast<const TapPtr*>(c->ring.dev + off + bytes_layers);
-        L.n_layers = (int)n_layers;
-        L.tokens = c->tokens;
-        L.total_wgs = wg;
-        L.wgs_per_xcd = (wg + 7) / 8;
+        Prepared pr;
+        pr.kd = kd;
+        memset(&pr.L, 0, sizeof pr.L);
+        pr.L.layers = reinterpret_cast<const TapLayer*>(c->ring.dev + off);
+        pr.L.ptrs = reinterpret_cast<const TapPtr*>(c->ring.dev + off + bytes_layers);
+        pr.L.n_layers = (int)n_layers;
+        pr.L.tokens = c->tokens;
+        pr.L.total_wgs = wg;
+        pr.L.wgs_per_xcd = (wg + 7) / 8;
+        pr.max_d = max_d;
+        pr.all_round = all_round;
+        pr.ring_begin = c->ring.cur_begin;
+        pr.ring_end = c->ring.cur_end;
+        prepared.push_back(pr);
+    }
+    // pass 2: one launch per kind.  A flush with several kinds (SD-v1.5: head_dim 40 / 80 / 160) has kernels of a
+    // few dozen to a few hundred workgroups x 50 sequential steps each, which leave most of the chip idle when run
+    // one after the other.  The largest stays on the caller's stream, every other kind gets its own auxiliary
+    // non-blocking stream, forked from / joined to the caller's stream by events (all tables are uploaded before
+    // the fork) and launched FIRST so that its few workgroups are resident when the large grid fills the rest.
+    const bool side = !rc && prepared.size() > 1 && prepared.size() <= (size_t)DaamCtx::kAux + 1 && !c->no_side_stream;
+    if (side && !c->aux_fork) {
+        hipError_t ae = hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming);
+        for (int i = 0; i < DaamCtx::kAux && ae == hipSuccess; ++i) {
+            ae = hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking);
+            if (ae == hipSuccess) ae = hipEventCreateWithFlags(&c->aux_join[i], hipEventDisableTiming);
+        }
+        if (ae != hipSuccess) rc = fail((int)ae, "auxiliary streams: %s", hipGetErrorString(ae));
+    }
+    size_t main_idx = 0;
+    for (size_t i = 1; i < prepared.size(); ++i)
+        if (prepared[i].L.total_wgs > prepared[main_idx].L.total_wgs) main_idx = i;
+    const bool ev_started = c->profile && !rc && !prepared.empty();
+    if (ev_started) (void)hipEventRecord(c->prof_ev[0][0], s);
+    bool forked = false;
+    if (side && !rc) {
+        if (hipEventRecord(c->aux_fork, s) != hipSuccess) rc = fail(DAAM_E_STATE, "stream fork failed");
+        else forked = true;
+    }
+    std::vector<size_t> launch_order;                        // side kinds first, the main one last
+    for (size_t i = 0; i < prepared.size(); ++i)
+        if (!forked || i != main_idx) launch_order.push_back(i);
+    if (forked) launch_order.push_back(main_idx);
+    int n_side = 0;
+    for (size_t pi : launch_order) {
+        if (rc) break;
+        const Prepared& pr = prepared[pi];
+        hipStream_t ks = s;
+        if (forked && pi != main_idx) {
+            ks = c->aux_stream[n_side];
+            if (hipStreamWaitEvent(ks, c->aux_fork, 0) != hipSuccess) { rc = fail(DAAM_E_STATE, "stream fork failed"); break; }
+        }
         int grid = 0;
-        e = (kd == 65 || kd == 66) ? launch_tap_d64(L, in_dtype, c->acc_dtype, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
-          : kd ? launch_tap_mfma(L, c->acc_dtype, max_d, c->fast_exp && all_round, s, &grid, &c->last_lds[0])
-               : launch_tap_generic(L, in_dtype, c->acc_dtype, max_d, s, &grid, &c->last_lds[0]);
+        hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
+                     : pr.kd ? launch_tap_mfma(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
+                             : launch_tap_generic(pr.L, in_dtype, c->acc_dtype, pr.max_d, ks, &grid, &c->last_lds[0]);
         grid_total += grid;
         if (e != hipSuccess) { rc = fail((int)e, "tap launch: %s", hipGetErrorString(e)); break; }
-        e = c->ring.release(s);
+        e = c->ring.release_range(pr.ring_begin, pr.ring_end, ks);
         if (e != hipSuccess) { rc = fail((int)e, "event record: %s", hipGetErrorString(e)); break; }
+        if (ks != s) {
+            if (hipEventRecord(c->aux_join[n_side], ks) != hipSuccess) { rc = fail(DAAM_E_STATE, "stream join failed"); break; }
+            ++n_side;
+        }
         for (size_t i = 0; i < order.size(); ++i)
-            if (kind[i] == kd) { c->layers[order[i]].dirty = true; c->layers[order[i]].zero_pending = false; }
+            if (kind[i] == pr.kd) { c->layers[order[i]].dirty = true; c->layers[order[i]].zero_pending = false; }
     }
+    // join (after the main kernel is enqueued): the caller's stream continues when every side kernel is done
+    for (int i = 0; i < n_side; ++i)
+        if (hipStreamWaitEvent(s, c->aux_join[i], 0) != hipSuccess) rc = rc ? rc : fail(DAAM_E_STATE, "stream join failed");
     if (c->profile && ev_started) (void)hipEventRecord(c->prof_ev[0][1], s);
     c->last_grid[0] = grid_total;
     c->last_block[0] = 256;
