@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from pathlib import Path
 from typing import Any, List, Optional, Type, Union
 
@@ -81,14 +82,17 @@ class DiffusionHeatMapHooker(AggregateHooker):
         self._gen_idx = 0
         self.tap_mode = tap
 
+        # the child hookers see this object through a weak proxy: no parent <-> child reference cycle, so a trace
+        # that goes out of scope releases its context and running sums immediately
+        me = weakref.proxy(self)
         hookers: List[ObjectHooker] = [
-            UNetCrossAttentionHooker(m, self, layer_idx=idx, latent_hw=self.latent_hw, load_heads=load_heads,
+            UNetCrossAttentionHooker(m, me, layer_idx=idx, latent_hw=self.latent_hw, load_heads=load_heads,
                                      save_heads=save_heads, data_dir=data_dir)
             for idx, m in enumerate(modules_found)
         ]
-        hookers.append(PipelineHooker(pipeline, self))
+        hookers.append(PipelineHooker(pipeline, me))
         if type(pipeline).__name__ == 'StableDiffusionXLPipeline':           # trace.py:55-56
-            hookers.append(ImageProcessorHooker(pipeline.image_processor, self))
+            hookers.append(ImageProcessorHooker(pipeline.image_processor, me))
         super().__init__(hookers)
         self.pipe = pipeline
 

@@ -293,6 +293,33 @@ def test_defer_byte_budget(fake_engine, monkeypatch, recorder):
     eng.close()
 
 
+def test_trace_and_engine_are_freed_without_gc(fake_engine):
+    """No reference cycles between trace, hookers, engine and the C++ recorder: dropping the last reference closes
+    the native context right away (the running sums of an SDXL trace are 221 MB)."""
+    import gc
+    import weakref
+    import daam_amd
+    from oracle import fake_diffusers as fd
+    E, lib = fake_engine
+    gc.collect()
+    gc.disable()
+    try:
+        eng = E.HeatMapEngine(2, defer_steps=4)
+        eng.tap_qk(0, torch.zeros(2, 64, 16, dtype=torch.float16), torch.zeros(2, 77, 16, dtype=torch.float16), 2, 0.35, 1)
+        ref = weakref.ref(eng)
+        del eng
+        assert ref() is None and lib.names()[-1] == 'daam_ctx_destroy'
+        pipe = fd.make_pipe('sd15', mini=True)
+        tc = daam_amd.trace(pipe)
+        tref, eref = weakref.ref(tc), weakref.ref(tc.engine)
+        with tc:
+            pass
+        del tc
+        assert tref() is None and eref() is None
+    finally:
+        gc.enable()
+
+
 def test_engine_immediate_mode_and_dtype_rules(fake_engine):
     E, lib = fake_engine
     eng = E.HeatMapEngine(2, defer_steps=0)
