@@ -420,30 +420,35 @@ def test_full_size_layer_properties(heads, side, d):
 from hypothesis import HealthCheck, given, settings, strategies as st
 
 
-@settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
 @given(heads=st.integers(1, 4), side=st.sampled_from([4, 8, 12, 16, 24]), d=st.sampled_from([8, 16, 24, 40, 64, 80]),
        batch=st.sampled_from([1, 2, 4]), steps=st.integers(1, 5), defer=st.sampled_from([0, 1, 2, 7]),
-       mode=st.sampled_from(['f16_exact', 'f16_f32acc', 'f32']), seed=st.integers(0, 2 ** 16))
+       mode=st.sampled_from(['f16_exact', 'f16_f32acc', 'f32', 'bf16_exact', 'bf16_f32acc']), seed=st.integers(0, 2 ** 16))
 def test_tap_property(heads, side, d, batch, steps, defer, mode, seed):
-    """Any (heads, map size, head_dim, CFG batch, steps, deferral) combination matches the oracle
+    """Any (heads, map size, head_dim, CFG batch, steps, deferral, pipeline dtype) combination matches the oracle
     within the stated tolerance and keeps the token sums at `steps`."""
     hw = side * side
     rng = np.random.default_rng(seed)
-    np_dt = np.float32 if mode == 'f32' else np.float16
-    acc_np = np.float16 if mode == 'f16_exact' else np.float32
+    np_dt = np.float32 if mode == 'f32' else ho.BF16 if mode.startswith('bf16') else np.float16
+    acc_np = np_dt if mode.endswith('_exact') else np.float32
     scale = d ** -0.5
     qs, ks = zip(*[_qk(rng, batch, heads, hw, d, np_dt) for _ in range(steps)])
     want = _oracle_steps(qs, ks, heads, scale, np_dt, acc_np).astype(np.float64)
-    eng = _engine(accumulate='exact' if mode != 'f16_f32acc' else 'float32', defer_steps=defer)
+    eng = _engine(accumulate='float32' if mode.endswith('_f32acc') else 'exact', defer_steps=defer)
     for q, k in zip(qs, ks):
-        eng.tap_qk(0, torch.from_numpy(q).to(DEV), torch.from_numpy(k).to(DEV), heads, scale, factor=1)
+        eng.tap_qk(0, _dev(q, np_dt), _dev(k, np_dt), heads, scale, factor=1)
     got = np.stack([v.float().cpu().numpy() for _, v in eng.items()]).astype(np.float64)
     eng.close()
     assert got.shape == want.shape
-    tol = {'f32': 2e-6 * max(1.0, np.abs(want).max()), 'f16_exact': 2.0 ** -10 * max(1.0, want.max()),
-           'f16_f32acc': steps * 2.0 ** -11}[mode]
+    half_ulp = 2.0 ** -8 if mode.startswith('bf16') else 2.0 ** -11
+    if mode == 'f32':
+        tol = 2e-6 * max(1.0, np.abs(want).max())
+    elif mode.endswith('_exact'):
+        tol = 2 * half_ulp * max(1.0, want.max())
+    else:
+        tol = steps * half_ulp
     assert np.abs(got - want).max() <= tol
-    np.testing.assert_allclose(got.sum(1), steps, atol=steps * 77 * 2.0 ** -11)
+    np.testing.assert_allclose(got.sum(1), steps, atol=steps * 77 * half_ulp)
 
 
 @settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
