@@ -24,6 +24,27 @@ __global__ __launch_bounds__(512) void k(int mode, int iters, float* sink) {
         }
         if (c0[0] + c1[1] + c2[2] + c3[3] == 1234.5f) *sink = 1.f;
     }
+    if (mode == 3 && wave < 4) {                              // ONE wave issues both, interleaved by the compiler
+        half8 a, b;
+        for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f); }
+        floatx4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+        float x0 = threadIdx.x * 0.25f, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f;
+        for (int it = 0; it < iters; ++it) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+            x0 = __builtin_fmaf(x0, 1.0001f, 0.5f); x1 = __builtin_fmaf(x1, 1.0001f, 0.5f);
+            x2 = __builtin_fmaf(x2, 1.0001f, 0.5f); x3 = __builtin_fmaf(x3, 1.0001f, 0.5f);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+            x0 = __builtin_fmaf(x0, 1.0001f, 0.5f); x1 = __builtin_fmaf(x1, 1.0001f, 0.5f);
+            x2 = __builtin_fmaf(x2, 1.0001f, 0.5f); x3 = __builtin_fmaf(x3, 1.0001f, 0.5f);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c2, 0, 0, 0);
+            x0 = __builtin_fmaf(x0, 1.0001f, 0.5f); x1 = __builtin_fmaf(x1, 1.0001f, 0.5f);
+            x2 = __builtin_fmaf(x2, 1.0001f, 0.5f); x3 = __builtin_fmaf(x3, 1.0001f, 0.5f);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c3, 0, 0, 0);
+            x0 = __builtin_fmaf(x0, 1.0001f, 0.5f); x1 = __builtin_fmaf(x1, 1.0001f, 0.5f);
+            x2 = __builtin_fmaf(x2, 1.0001f, 0.5f); x3 = __builtin_fmaf(x3, 1.0001f, 0.5f);
+        }
+        if (c0[0] + c1[1] + c2[2] + c3[3] + x0 + x1 + x2 + x3 == 1234.5f) *sink = 3.f;
+    }
     if (do_valu) {
         float x0 = threadIdx.x * 0.25f, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f;
         for (int it = 0; it < iters; ++it) {
@@ -43,7 +64,7 @@ int main() {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 200000;
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, mode, 1000, sink);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
@@ -53,7 +74,7 @@ int main() {
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("mode %d (%s): %.3f ms  -> %.1f ns per iteration (4 MFMA 16x16x32 and/or 16 v_fma)\n", mode,
-               mode == 0 ? "MFMA waves only" : mode == 1 ? "VALU waves only" : "both", ms, ms * 1e6 / iters);
+               mode == 0 ? "MFMA waves only" : mode == 1 ? "VALU waves only" : mode == 2 ? "both, different waves" : "both, same wave", ms, ms * 1e6 / iters);
     }
     return 0;
 }
