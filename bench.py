@@ -340,7 +340,7 @@ def main():
             gpu_bound_maps_per_s=round(1e3 / gpu_ms_per_gen, 1),
             host_enqueue_ms_per_generation=round(host_ms, 3),
             raw_maps_per_s=round(world * args.steps * args.denoise_steps * sum(h for _, h, _, _ in layers) / elapsed, 1),
-            roofline_finalize=dict(bound='hbm', kernel='table upload + zeroing, finalize_same_kernel, finalize_up32_mfma_kernel', achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
+            roofline_finalize=dict(bound='hbm', kernel='table upload + zeroing, finalize_up32_same_kernel (x2 MFMA class and same-size class in one launch)', achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
                                    unit='GB/s', frac=round(fin_gbs / HBM_PEAK_GBS, 4), bytes_per_launch=int(fin_bytes),
                                    ms_per_launch=round(fin_ms, 4)),
         )

@@ -29,6 +29,7 @@ bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, i
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
 hipError_t launch_upload(void* dst, const void* src_host_mapped, size_t bytes, void* zero, size_t zero_bytes, hipStream_t);
+hipError_t launch_finalize_up32_same(const FinLaunch& up, const FinLaunch& same, hipStream_t, int*);
 hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
 hipError_t launch_finalize_up(const FinLaunch&, int side, int, int mfma_ok, hipStream_t, int*);
 bool finalize_up_supported(int side, int out_side);
@@ -175,6 +176,7 @@ struct DaamCtx {
     void* d_up32_ops = nullptr;        // finalize_up32_mfma_kernel operands of the 32 -> 64 table (see build_up32_ops)
     int up32_tab = -1;
     int no_mfma_finalize = 0;
+    int no_paired_finalize = 0;       // debugging / A-B: same-size and x2 class as two launches
     std::vector<Pending> pending;
     std::vector<int> pending_count;   // per layer: recorded steps
     std::vector<int> pending_last;    // per layer: index of its newest entry in `pending`
@@ -292,6 +294,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->force_generic = fg && fg[0] == '1';
     const char* nm = getenv("DAAM_NO_MFMA_FINALIZE");
     c->no_mfma_finalize = nm && nm[0] == '1';
+    const char* npf = getenv("DAAM_NO_PAIRED_FINALIZE");
+    c->no_paired_finalize = npf && npf[0] == '1';
     const char* n16 = getenv("DAAM_NO_D64");            // debugging: 32x32-tile kernel also for head_dim 64
     c->no_d64 = n16 && n16[0] == '1';
     const char* nss = getenv("DAAM_NO_SIDE_STREAM");        // debugging / A-B: every tap kernel of a flush on the caller's stream
@@ -824,11 +828,13 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     c->last_grid[1] = 0;
     c->last_lds[1] = 0;
     static const int env_chunks = getenv("DAAM_FIN_CHUNKS") ? atoi(getenv("DAAM_FIN_CHUNKS")) : 0;
+    // build the launch descriptor of every non-empty class first
+    FinLaunch launches[4];
+    bool have[4] = {false, false, false, false};
     for (int cls = 0; cls < 4; ++cls) {
         const int n = (int)keys[cls].size();
-        if (n == 0) { continue; }
-
-        FinLaunch L;
+        if (n == 0) continue;
+        FinLaunch& L = launches[cls];
         L.keys = dev;
         dev += n;
         L.tab_idx = c->d_tab_idx;
@@ -840,22 +846,32 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         L.inv_n = 1.0f / (float)total;
         L.max_side = max_side;
         L.mfma_ops = (cls == 1 && keys[cls][0].tab == c->up32_tab) ? c->d_up32_ops : nullptr;
-        int grid = 0, lds = 0;
-        hipError_t e;
         if (cls == 0) {
             L.n_chunks = std::max(1, std::min(n, env_chunks ? env_chunks : 4));
-            e = launch_finalize_same(L, c->acc_dtype, s, &grid);
         } else if (cls == 3) {
             L.n_chunks = std::max(1, std::min(n, 32));
-            e = launch_finalize(L, c->acc_dtype, s, &grid, &lds);
         } else {
             // each wave takes keys first, first + 4*n_chunks, ...: at most 64 per wave.  ~1000 workgroups
-            // (two full rounds at 2 workgroups per CU) measured best: fewer leaves a ragged tail,
+            // (one full round at 4 workgroups per CU) measured best: fewer leaves a ragged tail,
             // more pays the per-workgroup reduction + atomics too often.
             const int want = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
             L.n_chunks = std::max(std::max(1, std::min((n + 3) / 4, want)), (n + 127) / 128);   // <= 64 keys per wave (2 or 4 key lanes per workgroup)
-            e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, c->tab_fp16_exact[keys[cls][0].tab] && !c->no_mfma_finalize, s, &grid);
         }
+        have[cls] = true;
+    }
+    const bool mfma_up = have[1] && c->acc_dtype == DAAM_F16 && launches[1].mfma_ops &&
+                         c->tab_fp16_exact[keys[1][0].tab] && !c->no_mfma_finalize;
+    // SDXL-1024 in fp16: the same-size and the x2 class side by side in ONE launch
+    const bool paired = mfma_up && have[0] && !c->no_paired_finalize;
+    for (int cls = 0; cls < 4; ++cls) {
+        if (!have[cls] || (paired && cls == 0)) continue;
+        const FinLaunch& L = launches[cls];
+        int grid = 0, lds = 0;
+        hipError_t e;
+        if (cls == 1 && paired) e = launch_finalize_up32_same(L, launches[0], s, &grid);
+        else if (cls == 0) e = launch_finalize_same(L, c->acc_dtype, s, &grid);
+        else if (cls == 3) e = launch_finalize(L, c->acc_dtype, s, &grid, &lds);
+        else e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, c->tab_fp16_exact[keys[cls][0].tab] && !c->no_mfma_finalize, s, &grid);
         if (e != hipSuccess) return fail((int)e, "finalize launch (class %d): %s", cls, hipGetErrorString(e));
         c->last_grid[1] += grid;
         c->last_lds[1] = std::max(c->last_lds[1], lds);

@@ -289,7 +289,8 @@ __device__ __forceinline__ half2v fin_cvt_pk(float a, float b) {
     return r;
 }
 
-__global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLaunch L)
+// body: workgroup (tok, chunk) of n_chunks key chunks
+__device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, const int tok, const int chunk, const int n_chunks)
 {
     // wave = (nt, kq): output columns [32nt, 32nt+32) of every second key of the workgroup's chunk.  Half the
     // output per wave keeps the kernel under 128 VGPRs (4 waves per SIMD: the MFMA chain of one wave
@@ -302,7 +303,6 @@ __global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLau
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, g = lane >> 5;
     const int nt = wave & 1, kq = wave >> 1;
-    const int tok = blockIdx.x;
     DAAM_FT(0);
 
     // operand pieces of the banded tap matrix, built on the host (build_up32_ops in daam_api.hip):
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLau
 
     floatx16 acc[2] = {floatx16{0}, floatx16{0}};             // [mt]
 
-    const int stride = gridDim.y * 2;
-    const int first = blockIdx.y * 2 + kq;
+    const int stride = n_chunks * 2;
+    const int first = chunk * 2 + kq;
     const int nk = first < L.n_keys ? min((L.n_keys - first + stride - 1) / stride, kMaxKeysPerWave) : 0;
     if (nt == 0 && lane < nk) kbase[kq][lane] = as_global<FinKey>(L.keys)[first + lane * stride].base;
     __syncthreads();
@@ -384,6 +384,11 @@ __global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLau
     DAAM_FT(3);
 }
 
+__global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLaunch L)
+{
+    finalize_up32_mfma_body(L, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
 #ifdef DAAM_FIN_TIMING
 }  // namespace daam
 extern "C" int daam_debug_dump_fin(unsigned long long* dst) {
@@ -397,7 +402,7 @@ namespace daam {
 // lane; the partial sums are transposed through a wave-private LDS tile so that the final
 // atomics are 256-byte coalesced rows instead of 64 scattered 32-byte sectors.
 template <typename ACC_T>
-__global__ __launch_bounds__(256) void finalize_same_kernel(const FinLaunch L)
+__device__ __forceinline__ void finalize_same_body(const FinLaunch& L, const int bx, const int by, const int ny)
 {
     using P = Plane<ACC_T>;
     constexpr int E = P::kPerPiece;
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) void finalize_same_kernel(const FinLaunch L)
     __shared__ float tile[4][64 * (E + 1)];
     const int plane = L.out_side * L.out_side;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wave_id = blockIdx.x * 4 + wave;                 // wave -> 64 pieces
+    const int wave_id = bx * 4 + wave;                         // wave -> 64 pieces
     const int per_tok = plane / E;                             // pieces per token plane
     const int waves_per_tok = (per_tok + 63) / 64;             // a wave never straddles two token planes
     const int tok = wave_id / waves_per_tok;
@@ -416,8 +421,8 @@ __global__ __launch_bounds__(256) void finalize_same_kernel(const FinLaunch L)
     float a[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) a[i] = 0.f;
-    const int stride = gridDim.y;
-    for (int k0 = blockIdx.y; k0 < L.n_keys; k0 += stride * kBatch) {
+    const int stride = ny;
+    for (int k0 = by; k0 < L.n_keys; k0 += stride * kBatch) {
         typename P::Piece buf[kBatch];
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
@@ -440,6 +445,55 @@ __global__ __launch_bounds__(256) void finalize_same_kernel(const FinLaunch L)
         const int e = i * 64 + lane;                           // element of the wave's contiguous span
         if (e < span) atomicAdd(out + e, t[(e / E) * (E + 1) + (e % E)]);
     }
+}
+
+template <typename ACC_T>
+__global__ __launch_bounds__(256) void finalize_same_kernel(const FinLaunch L)
+{
+    finalize_same_body<ACC_T>(L, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// SDXL-1024 in fp16 has exactly two key classes: 64x64 planes (same size: an HBM stream) and 32x32 planes (x2 on the
+// matrix cores: issue-bound).  One launch runs both side by side -- workgroups [0, up_blocks) are the x2 body, the rest
+// the same-size body -- instead of two launches whose tails / ramps add up (measured 68 + 19 us back to back).
+struct FinPair {
+    FinLaunch up, same;
+    int32_t up_blocks, same_gx, same_gy;
+};
+
+__global__ __launch_bounds__(256, 4) void finalize_up32_same_kernel(const FinPair P)
+{
+    const int b = blockIdx.x;
+    if (b < P.up_blocks) {
+        finalize_up32_mfma_body(P.up, b % P.up.tokens, b / P.up.tokens, P.up.n_chunks);
+    } else {
+        const int r = b - P.up_blocks;
+        finalize_same_body<_Float16>(P.same, r % P.same_gx, r / P.same_gx, P.same_gy);
+    }
+}
+
+static void same_grid(const FinLaunch& L, int acc_dtype, int* gx, int* gy)
+{
+    const int plane = L.out_side * L.out_side;
+    const int per = acc_dtype == 1 ? 4 : 8;
+    // waves never straddle token planes: per-token piece count rounded up to whole waves
+    const int waves = L.tokens * ((plane / per + 63) / 64);
+    *gx = (waves + 3) / 4;
+    *gy = L.n_chunks;
+}
+
+// both fp16 classes of an SDXL-1024 finalize in one launch (up: x2 MFMA class, same: same-size class)
+hipError_t launch_finalize_up32_same(const FinLaunch& up, const FinLaunch& same, hipStream_t stream, int* grid_out)
+{
+    FinPair P;
+    P.up = up;
+    P.same = same;
+    P.up_blocks = up.tokens * up.n_chunks;
+    same_grid(same, 0, &P.same_gx, &P.same_gy);
+    const int grid = P.up_blocks + P.same_gx * P.same_gy;
+    *grid_out = grid;
+    hipLaunchKernelGGL(finalize_up32_same_kernel, dim3(grid), dim3(256), 0, stream, P);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ def find(d, suffix):
 def short(name):
     if 'daam' not in name:
         return None
-    for k in ('tap_d64_kernel', 'tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'finalize_up32_mfma_kernel',
+    for k in ('tap_d64_kernel', 'tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'finalize_up32_same_kernel', 'finalize_up32_mfma_kernel',
               'finalize_up_kernel', 'finalize_same_kernel', 'finalize_kernel', 'normalize_kernel', 'word_'):
         if k in name:
             return k
@@ -72,7 +72,8 @@ def main():
         traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
         rec = {}
         for kern, field in (('tap_d64_kernel', 'tap'), ('tap_mfma_kernel', 'tap'),
-                            ('finalize_up32_mfma_kernel', 'finalize_up'), ('finalize_same_kernel', 'finalize_same')):
+                            ('finalize_up32_same_kernel', 'finalize_pair'), ('finalize_up32_mfma_kernel', 'finalize_up'),
+                            ('finalize_same_kernel', 'finalize_same')):
             cs = pmc.get(kern, {})
             if f'{field}_bytes_per_launch' in rec:
                 continue
