@@ -320,6 +320,33 @@ def test_trace_and_engine_are_freed_without_gc(fake_engine):
         gc.enable()
 
 
+def test_defer_budget_defaults(monkeypatch):
+    """$DAAM_DEFER_BYTES wins; otherwise 32 GiB capped at a quarter of the free device memory (at least 1 GiB)."""
+    from daam_amd import trace as T
+
+    class _P:
+        device = torch.device('cuda', 0)
+
+    class _Pipe:
+        class unet:
+            @staticmethod
+            def parameters():
+                return iter([_P()])
+
+    monkeypatch.delenv('DAAM_DEFER_BYTES', raising=False)
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda dev: (200 << 30, 288 << 30))
+    assert T._default_defer_bytes(_Pipe()) == 32 << 30
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda dev: (40 << 30, 288 << 30))
+    assert T._default_defer_bytes(_Pipe()) == 10 << 30
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda dev: (1 << 30, 288 << 30))
+    assert T._default_defer_bytes(_Pipe()) == 1 << 30
+    assert T._default_defer_bytes(object()) == 32 << 30            # no parameters to ask: the default
+    monkeypatch.setenv('DAAM_DEFER_BYTES', str(5 << 30))
+    assert T._default_defer_bytes(_Pipe()) == 5 << 30
+    monkeypatch.setenv('DAAM_DEFER_STEPS', '7')
+    assert T._default_defer() == 7
+
+
 def test_engine_immediate_mode_and_dtype_rules(fake_engine):
     E, lib = fake_engine
     eng = E.HeatMapEngine(2, defer_steps=0)
