@@ -322,7 +322,9 @@ def test_trace_and_engine_are_freed_without_gc(fake_engine):
 
 def test_defer_budget_defaults(monkeypatch):
     """$DAAM_DEFER_BYTES wins; otherwise 32 GiB capped at a quarter of the free device memory (at least 1 GiB)."""
-    from daam_amd import trace as T
+    import sys
+    import daam_amd  # noqa: F401
+    T = sys.modules['daam_amd.trace']          # `daam_amd.trace` the NAME is the class, like the reference's
 
     class _P:
         device = torch.device('cuda', 0)
