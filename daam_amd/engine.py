@@ -8,6 +8,7 @@ reference keeps in ``RawHeatMapCollection`` (daam/heatmap.py:148-172) plus the b
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
 import math
 import os
@@ -26,15 +27,37 @@ Key = Tuple[int, int, int]   # (factor, layer, head) -- daam/heatmap.py:145
 _DTYPE_CODE = {torch.float16: nat.DAAM_F16, torch.float32: nat.DAAM_F32, torch.bfloat16: nat.DAAM_BF16}
 
 
+# Parked native contexts (with their running-sum buffers) of closed engines, per (device, layers, tokens, map side,
+# sum dtype).  A pipeline is usually traced once per generation: re-adopting the previous trace's context saves the
+# 1.5 ms of set-up / tear-down and the device synchronisation that destroying a context implies (hipFree).
+_PARKED: Dict[tuple, list] = {}
+_PARK_LIMIT = 2
+
+
+def _destroy_parked() -> None:
+    for states in _PARKED.values():
+        for st in states:
+            try:
+                st['lib'].daam_ctx_destroy(st['ctx'])
+            except Exception:
+                pass
+    _PARKED.clear()
+
+
+atexit.register(_destroy_parked)
+
+
 class HeatMapEngine:
     def __init__(self, n_layers: int, tokens: int = 77, out_side: int = 64, accumulate: str = 'exact',
-                 defer_steps: int = 0, defer_bytes: int = 32 << 30):
+                 defer_steps: int = 0, defer_bytes: int = 32 << 30, reuse_context: bool = False):
         """``accumulate``: ``'exact'`` keeps the running sums in the pipeline dtype like the
         reference (fp16 sums on an fp16 pipeline, heatmap.py:156); ``'float32'`` is the
         accuracy mode.  ``defer_steps`` > 0 records Q/K pointers and taps ``defer_steps``
         denoising steps of all layers in one launch (at most 64); the Q / K of the recorded steps stay
         alive until then, and a launch is forced at the next step boundary once they add up to
-        ``defer_bytes`` (both CFG halves count: 388 MB per SDXL-1024 step)."""
+        ``defer_bytes`` (both CFG halves count: 388 MB per SDXL-1024 step).  ``reuse_context``: ``close()`` parks
+        the native context and the sum buffers for the next engine of the same geometry instead of destroying them
+        (what ``trace`` asks for: one trace per generation is the normal use)."""
         if accumulate not in ('exact', 'float32'):
             raise ValueError("accumulate must be 'exact' or 'float32'")
         self.lib = nat.load()
@@ -44,6 +67,7 @@ class HeatMapEngine:
         self.accumulate = accumulate
         self.defer_steps = min(int(defer_steps), 64)     # the kernels stage at most 64 steps of pointers per launch
         self.defer_bytes = int(defer_bytes) if defer_bytes and defer_bytes > 0 else 1 << 62
+        self.reuse_context = bool(reuse_context) and not os.environ.get('DAAM_NO_CTX_POOL')
         self._held = 0                                    # bytes of recorded Q / K (Python recorder)
         self.ctx: Optional[nat.c_void_p] = None
         self.device: Optional[torch.device] = None
@@ -98,6 +122,12 @@ class HeatMapEngine:
         if pipe_dtype not in _DTYPE_CODE:
             raise RuntimeError(f'daam_amd: unsupported pipeline dtype {pipe_dtype} (fp16 / bf16 / fp32 only)')
         self.acc_dtype = torch.float32 if self.accumulate == 'float32' else pipe_dtype
+        parked = _PARKED.get(self._park_key()) if self.reuse_context else None
+        if parked:
+            st = parked.pop()
+            self.ctx, self.acc, self.layer_info = st['ctx'], st['acc'], st['layer_info']
+            nat.check(self.lib.daam_reset(self.ctx, self.stream))      # sums start from zero (lazily, like clear())
+            return
         ctx = nat.c_void_p()
         with torch.cuda.device(self.device):
             nat.check(self.lib.daam_ctx_create(self.n_layers, self.tokens, self.out_side,
@@ -105,9 +135,17 @@ class HeatMapEngine:
                                                nat.byref(ctx)))
         self.ctx = ctx
 
+    def _park_key(self) -> tuple:
+        return (str(self.device), self.n_layers, self.tokens, self.out_side, self.acc_dtype)
+
     def close(self) -> None:
         if self.ctx is not None:
-            self.lib.daam_ctx_destroy(self.ctx)
+            states = _PARKED.setdefault(self._park_key(), []) if self.reuse_context else None
+            if states is not None and len(states) < _PARK_LIMIT:
+                states.append(dict(lib=self.lib, ctx=self.ctx, acc=self.acc, layer_info=self.layer_info))
+                self.acc, self.layer_info = {}, {}
+            else:
+                self.lib.daam_ctx_destroy(self.ctx)
             self.ctx = None
         self.acc.clear()
         self.layer_info.clear()

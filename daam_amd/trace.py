@@ -74,7 +74,7 @@ class DiffusionHeatMapHooker(AggregateHooker):
         self.engine = HeatMapEngine(max(1, len(modules_found)), tokens=77, out_side=int(math.sqrt(self.latent_hw)),
                                     accumulate=accumulate,
                                     defer_steps=_default_defer() if defer_steps is None else defer_steps,
-                                    defer_bytes=_default_defer_bytes(pipeline))
+                                    defer_bytes=_default_defer_bytes(pipeline), reuse_context=True)
         self.all_heat_maps = RawHeatMapCollection(self.engine)
         self.last_prompt: str = ''
         self.last_image = None
