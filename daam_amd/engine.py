@@ -8,7 +8,6 @@ reference keeps in ``RawHeatMapCollection`` (daam/heatmap.py:148-172) plus the b
 """
 from __future__ import annotations
 
-import atexit
 import ctypes
 import math
 import os
@@ -34,17 +33,13 @@ _PARKED: Dict[tuple, list] = {}
 _PARK_LIMIT = 2
 
 
-def _destroy_parked() -> None:
+def release_parked_contexts() -> None:
+    """Destroy every parked context now (frees their sum buffers too).  Not called at interpreter exit on purpose:
+    process teardown reclaims them, and no HIP call has to run while the runtime is shutting down."""
     for states in _PARKED.values():
         for st in states:
-            try:
-                st['lib'].daam_ctx_destroy(st['ctx'])
-            except Exception:
-                pass
+            st['lib'].daam_ctx_destroy(st['ctx'])
     _PARKED.clear()
-
-
-atexit.register(_destroy_parked)
 
 
 class HeatMapEngine:
