@@ -320,6 +320,36 @@ def test_trace_and_engine_are_freed_without_gc(fake_engine):
         gc.enable()
 
 
+def test_context_reuse_between_engines(fake_engine):
+    """``reuse_context=True`` (what ``trace`` uses): a closed engine parks its native context + sum buffers, the next
+    engine of the same geometry adopts them (reset, no new context); a different geometry gets its own."""
+    E, lib = fake_engine
+    E._PARKED.clear()
+    q, k = torch.zeros(2, 64, 16, dtype=torch.float16), torch.zeros(2, 77, 16, dtype=torch.float16)
+    a = E.HeatMapEngine(2, defer_steps=4, reuse_context=True)
+    a.tap_qk(0, q, k, 2, 0.35, 1)
+    buf = a.acc[0]
+    a.close()
+    assert 'daam_ctx_destroy' not in lib.names() and sum(len(v) for v in E._PARKED.values()) == 1
+    b = E.HeatMapEngine(2, defer_steps=4, reuse_context=True)
+    n_create = lib.names().count('daam_ctx_create')
+    b.tap_qk(0, q, k, 2, 0.35, 1)
+    assert lib.names().count('daam_ctx_create') == n_create            # adopted, not created
+    assert 'daam_reset' in lib.names() and b.acc[0] is buf and not E._PARKED[b._park_key()]
+    assert lib.names().count('daam_layer_configure') == 1               # same layer geometry: buffer kept
+    c = E.HeatMapEngine(3, defer_steps=4, reuse_context=True)           # other geometry: its own context
+    c.tap_qk(0, q, k, 2, 0.35, 1)
+    assert lib.names().count('daam_ctx_create') == n_create + 1
+    d = E.HeatMapEngine(2, defer_steps=4)                               # reuse not requested: plain create / destroy
+    d.tap_qk(0, q, k, 2, 0.35, 1)
+    d.close()
+    assert lib.names()[-1] == 'daam_ctx_destroy'
+    b.close(); c.close()
+    assert sum(len(v) for v in E._PARKED.values()) == 2
+    E.release_parked_contexts()
+    assert not E._PARKED and lib.names().count('daam_ctx_destroy') == 3
+
+
 def test_defer_budget_defaults(monkeypatch):
     """$DAAM_DEFER_BYTES wins; otherwise 32 GiB capped at a quarter of the free device memory (at least 1 GiB)."""
     import sys
