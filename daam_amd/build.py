@@ -58,7 +58,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     build_fastpath(force, verbose)
     if not force and not stale():
         return OUT
-    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fvisibility=hidden',
            *[os.path.join(HERE, 'csrc', f) for f in SOURCES], '-o', OUT]
     if verbose:
         print(' '.join(cmd), flush=True)

@@ -166,6 +166,7 @@ constexpr int kMaxTabs = 16;
 }  // namespace
 
 struct DaamCtx {
+    int device = 0;                    // HIP device the context was created on; every entry point runs there
     int max_layers, tokens, out_side, acc_dtype;
     std::vector<Layer> layers;
     Ring ring;
@@ -192,6 +193,19 @@ struct DaamCtx {
     int force_generic = 0;
     int fast_exp = 0;
     int no_d64 = 0;
+};
+
+// Entry points may be called with another device current (a pipeline on cuda:1 while the process default is
+// cuda:0): streams, events and launches must go to the context's device.  Restores the caller's device on exit.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const DaamCtx* c) {
+        if (c && hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
 static size_t acc_elem(int dtype) { return dtype == DAAM_F32 ? 4 : 2; }
@@ -278,6 +292,7 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail((int)hipErrorNoDevice, "no HIP device");
     DaamCtx* c = new DaamCtx();
+    HIP_TRY(hipGetDevice(&c->device));
     c->max_layers = max_layers;
     c->tokens = tokens;
     c->out_side = out_side;
@@ -314,6 +329,7 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
 int daam_ctx_destroy(DaamCtx* c)
 {
     if (!c) return 0;
+    DeviceGuard on_device(c);
     (void)hipDeviceSynchronize();
     c->ring.destroy();
     for (auto& l : c->layers)
@@ -338,6 +354,7 @@ int daam_layer_configure(DaamCtx* c, int layer, int heads, int side, int factor,
     if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
     if (layer < 0 || layer >= c->max_layers) return fail(DAAM_E_INVALID, "layer %d out of range", layer);
     if (heads <= 0 || side <= 0 || side > 1024) return fail(DAAM_E_INVALID, "heads %d / side %d", heads, side);
+    DeviceGuard on_device(c);
     for (auto& p : c->pending)
         if (p.layer == layer) return fail(DAAM_E_STATE, "layer %d re-configured with un-flushed taps pending", layer);
     Layer& l = c->layers[layer];
@@ -395,12 +412,21 @@ int daam_layer_acc(DaamCtx* c, int layer, void** acc, size_t* bytes)
 {
     if (!c || layer < 0 || layer >= c->max_layers || !c->layers[layer].configured)
         return fail(DAAM_E_STATE, "layer %d not configured", layer);
-    {
-        int zrc = ensure_zeroed(c->layers[layer], nullptr);
-        if (zrc) return zrc;
-    }
     if (acc) *acc = c->layers[layer].acc;
     if (bytes) *bytes = c->layers[layer].bytes;
+    return 0;
+}
+
+int daam_layer_touch(DaamCtx* c, int layer, void* stream)
+{
+    if (!c || layer < 0 || layer >= c->max_layers || !c->layers[layer].configured)
+        return fail(DAAM_E_STATE, "layer %d not configured", layer);
+    if (!c->pending.empty()) return fail(DAAM_E_STATE, "layer touched with deferred taps pending: flush first");
+    DeviceGuard on_device(c);
+    Layer& l = c->layers[layer];
+    int zrc = ensure_zeroed(l, (hipStream_t)stream);       // a reset still owed to the buffer happens first, on this stream
+    if (zrc) return zrc;
+    l.dirty = true;                                        // later taps add to the sums, the next reset clears them
     return 0;
 }
 
@@ -500,6 +526,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     int rc = check_qk(c, layer, q, k, d);
     if (rc) return rc;
     if (!c->pending.empty()) return fail(DAAM_E_STATE, "immediate tap with deferred taps pending: flush first");
+    DeviceGuard on_device(c);
     const bool mfma = use_mfma(c, *d, q, k);
     if (!mfma && (rc = ensure_zeroed(c->layers[layer], (hipStream_t)stream))) return rc;
     TapLaunch L;
@@ -584,6 +611,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
 {
     if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
     if (c->pending.empty()) return 0;
+    DeviceGuard on_device(c);
     hipStream_t s = (hipStream_t)stream;
     const int in_dtype = c->pending.front().d.in_dtype;
     // group the recorded calls by layer (first-seen order, steps in recorded order), and the
@@ -742,6 +770,7 @@ int daam_tap_probs(DaamCtx* c, int layer, const void* probs, int in_dtype, int b
     if (batch_heads - batch_heads / 2 != l.heads || hw != l.hw)
         return fail(DAAM_E_INVALID, "layer %d is [%d heads, %d positions], call has [%d kept, %d]", layer, l.heads, l.hw,
                     batch_heads - batch_heads / 2, hw);
+    DeviceGuard on_device(c);
     {
         int zrc = ensure_zeroed(c->layers[layer], (hipStream_t)stream);
         if (zrc) return zrc;
@@ -780,6 +809,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
 {
     if (!c || !out) return fail(DAAM_E_INVALID, "NULL argument");
     if (!c->pending.empty()) return fail(DAAM_E_STATE, "finalize with deferred taps pending: flush first");
+    DeviceGuard on_device(c);
     for (auto& l : c->layers)
         if (l.configured) {
             int zrc = ensure_zeroed(l, (hipStream_t)stream);
@@ -822,7 +852,13 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         for (auto& v : keys) { memcpy(dst, v.data(), v.size() * sizeof(FinKey)); dst += v.size(); }
     }
     if (c->profile) (void)hipEventRecord(c->prof_ev[1][0], s);    // timed: table upload + zeroing + the class kernels
-    HIP_TRY(c->ring.commit(off, bytes, s, zero_in_upload ? out : nullptr, zero_in_upload ? out_bytes : 0));
+    {
+        hipError_t ce = c->ring.commit(off, bytes, s, zero_in_upload ? out : nullptr, zero_in_upload ? out_bytes : 0);
+        if (ce != hipSuccess) {
+            (void)c->ring.release(s);
+            return fail((int)ce, "table upload: %s", hipGetErrorString(ce));
+        }
+    }
     const FinKey* dev = reinterpret_cast<const FinKey*>(c->ring.dev + off);
     c->last_block[1] = 256;
     c->last_grid[1] = 0;
@@ -872,7 +908,10 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         else if (cls == 0) e = launch_finalize_same(L, c->acc_dtype, s, &grid);
         else if (cls == 3) e = launch_finalize(L, c->acc_dtype, s, &grid, &lds);
         else e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, c->tab_fp16_exact[keys[cls][0].tab] && !c->no_mfma_finalize, s, &grid);
-        if (e != hipSuccess) return fail((int)e, "finalize launch (class %d): %s", cls, hipGetErrorString(e));
+        if (e != hipSuccess) {
+            (void)c->ring.release(s);                      // the table region is reusable once whatever did launch has run
+            return fail((int)e, "finalize launch (class %d): %s", cls, hipGetErrorString(e));
+        }
         c->last_grid[1] += grid;
         c->last_lds[1] = std::max(c->last_lds[1], lds);
     }
@@ -904,6 +943,7 @@ int daam_word_heat_map(const float* maps, int side, const int32_t* idx, int n_id
 int daam_profile_enable(DaamCtx* c, int on)
 {
     if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
+    DeviceGuard on_device(c);
     if (on && !c->prof_ev[0][0])
         for (auto& pair : c->prof_ev)
             for (auto& ev : pair) HIP_TRY(hipEventCreate(&ev));

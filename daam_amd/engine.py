@@ -38,7 +38,7 @@ def release_parked_contexts() -> None:
     process teardown reclaims them, and no HIP call has to run while the runtime is shutting down."""
     for states in _PARKED.values():
         for st in states:
-            st['lib'].daam_ctx_destroy(st['ctx'])
+            st['lib'].daam_ctx_destroy(st['ctx'])        # synchronises the device first
     _PARKED.clear()
 
 
@@ -63,6 +63,11 @@ class HeatMapEngine:
         self.defer_steps = min(int(defer_steps), 64)     # the kernels stage at most 64 steps of pointers per launch
         self.defer_bytes = int(defer_bytes) if defer_bytes and defer_bytes > 0 else 1 << 62
         self.reuse_context = bool(reuse_context) and not os.environ.get('DAAM_NO_CTX_POOL')
+        # debugging aid: remember tensor._version of every recorded Q / K and refuse to launch when one was written in
+        # place between the processor call and the launch (deferred taps read them at launch time)
+        self._check_versions = bool(os.environ.get('DAAM_CHECK_VERSIONS'))
+        self._rec_stream: Optional[torch.cuda.Stream] = None   # stream the generation's Q / K are produced on
+        self._views_out = False                           # all_heat_maps handed out views of the live sum buffers
         self._held = 0                                    # bytes of recorded Q / K (Python recorder)
         self.ctx: Optional[nat.c_void_p] = None
         self.device: Optional[torch.device] = None
@@ -82,7 +87,7 @@ class HeatMapEngine:
         # slow path (first call of a layer, shape changes) and the fallback.  Both only record host-side
         # pointers -- all arithmetic is in libdaam_hip either way.
         self._fast = None
-        if self.defer_steps and not os.environ.get('DAAM_NO_FASTPATH'):
+        if self.defer_steps and not os.environ.get('DAAM_NO_FASTPATH') and not self._check_versions:
             try:
                 from . import _fastpath
             except ImportError:
@@ -121,6 +126,8 @@ class HeatMapEngine:
         if parked:
             st = parked.pop()
             self.ctx, self.acc, self.layer_info = st['ctx'], st['acc'], st['layer_info']
+            # whatever the previous owner queued (on its stream) comes first
+            self._current_stream().wait_event(st['event'])
             nat.check(self.lib.daam_reset(self.ctx, self.stream))      # sums start from zero (lazily, like clear())
             return
         ctx = nat.c_void_p()
@@ -135,9 +142,14 @@ class HeatMapEngine:
 
     def close(self) -> None:
         if self.ctx is not None:
-            states = _PARKED.setdefault(self._park_key(), []) if self.reuse_context else None
+            # a context whose sum buffers were handed out as views (all_heat_maps iteration) is not parked: the next
+            # owner would overwrite what those views show.  Destroying the context leaves the (torch-owned) buffers
+            # to the views.
+            park = self.reuse_context and not self._views_out
+            states = _PARKED.setdefault(self._park_key(), []) if park else None
             if states is not None and len(states) < _PARK_LIMIT:
-                states.append(dict(lib=self.lib, ctx=self.ctx, acc=self.acc, layer_info=self.layer_info))
+                done = self._current_stream().record_event()
+                states.append(dict(lib=self.lib, ctx=self.ctx, acc=self.acc, layer_info=self.layer_info, event=done))
                 self.acc, self.layer_info = {}, {}
             else:
                 self.lib.daam_ctx_destroy(self.ctx)
@@ -152,14 +164,20 @@ class HeatMapEngine:
         self._drop_recorded()
 
     def __del__(self):
+        import sys
+        if sys.is_finalizing():          # no HIP calls while the interpreter (and the HIP runtime) shut down
+            return
         try:
             self.close()
         except Exception:
             pass
 
+    def _current_stream(self) -> 'torch.cuda.Stream':
+        return torch.cuda.current_stream(self.device)
+
     @property
     def stream(self) -> int:
-        return torch.cuda.current_stream(self.device).cuda_stream
+        return self._current_stream().cuda_stream
 
     def _ensure_layer(self, layer: int, heads: int, side: int, factor: int) -> None:
         info = self.layer_info.get(layer)
@@ -176,6 +194,9 @@ class HeatMapEngine:
 
     def _touch(self, layer: int) -> None:
         if not self._touched_flag[layer]:
+            if not self.touched:
+                # first tap of a generation: this is the stream its Q / K are produced on (see flush)
+                self._rec_stream = self._current_stream()
             self._touched_flag[layer] = True
             self.touched.append(layer)
 
@@ -189,6 +210,15 @@ class HeatMapEngine:
             self._fast.reset_touched()
         if self.ctx is not None:
             nat.check(self.lib.daam_reset(self.ctx, self.stream))
+        if self._views_out:
+            # the reference's clear() drops its dict and the tensors it handed out live on unchanged
+            # (heatmap.py:170-172): leave the old buffers to those views and start the next generation on new ones
+            self.acc, self.layer_info = {}, {}
+            self._qk_cache = [None] * self.n_layers
+            self._mask_cache.clear()
+            if self._fast is not None:
+                self._fast.invalidate()
+            self._views_out = False
 
     # ---- tap -------------------------------------------------------------------------------------
     def tap_qk(self, layer: int, query: torch.Tensor, key: torch.Tensor, heads: int, scale: float,
@@ -217,7 +247,10 @@ class HeatMapEngine:
                 n = 0
             cnt[layer] = n + 1
             self._held += c[12]
-            self._rec.append((layer, query, key, c[9]))
+            if self._check_versions:
+                self._rec.append((layer, query, key, c[9], query._version, key._version))
+            else:
+                self._rec.append((layer, query, key, c[9]))
         else:
             rc = self.lib.daam_tap_qk(self.ctx, layer, query.data_ptr(), key.data_ptr(), c[7], self.stream)
             if rc:
@@ -293,6 +326,18 @@ class HeatMapEngine:
         self._qk_cache[layer] = entry
         return query, key, entry
 
+    def _launch_stream(self):
+        """The stream a deferred launch goes to, ordered after the producers of the recorded Q / K: normally the
+        current stream IS the stream they were produced on; when the maps are read from another stream (generation
+        inside ``torch.cuda.stream(s)``, ``compute_global_heat_map`` outside), the launch waits for everything queued
+        on the recording stream so far.  Returns ``(stream handle, recording stream or None)``."""
+        cur = self._current_stream()
+        rec = self._rec_stream
+        if rec is None or rec.cuda_stream == cur.cuda_stream:
+            return cur.cuda_stream, None
+        cur.wait_stream(rec)
+        return cur.cuda_stream, rec
+
     def flush(self) -> None:
         """Run every recorded (deferred) tap; the held Q/K references are dropped afterwards
         (stream order keeps their memory valid until the kernel has consumed it)."""
@@ -301,8 +346,12 @@ class HeatMapEngine:
             if self.ctx is None or n == 0:
                 return
             try:
+                stream, rec_stream = self._launch_stream()
                 nat.check(self.lib.daam_tap_qk_enqueue_many(self.ctx, n, la, qa, ka, da))
-                nat.check(self.lib.daam_tap_flush(self.ctx, self.stream))
+                nat.check(self.lib.daam_tap_flush(self.ctx, stream))
+                if rec_stream is not None:
+                    # the Q / K blocks return to the recording stream's allocator pool: not before the tap has read them
+                    rec_stream.wait_stream(self._current_stream())
                 self._set_window(self.defer_steps)
             finally:
                 self._drop_recorded()
@@ -311,15 +360,25 @@ class HeatMapEngine:
         n = len(rec)
         if self.ctx is None or n == 0:
             return
+        if self._check_versions:
+            for layer, q, k, _d, qv, kv in rec:
+                if q._version != qv or k._version != kv:
+                    self._drop_recorded()
+                    raise RuntimeError(f'daam_amd: the query / key of layer {layer} was modified in place between its '
+                                       'attention call and the deferred tap launch (use defer_steps=0 for such a pipeline)')
+            rec = [r[:4] for r in rec]
         lay_t, q_t, k_t, d_t = zip(*rec)                       # one C-level pass
         layers = np.array(lay_t, dtype=np.int32)
         qp = np.array([t.data_ptr() for t in q_t], dtype=np.uint64)
         kp = np.array([t.data_ptr() for t in k_t], dtype=np.uint64)
         dp = np.array(d_t, dtype=np.uint64)
         try:
+            stream, rec_stream = self._launch_stream()
             nat.check(self.lib.daam_tap_qk_enqueue_many(self.ctx, n, layers.ctypes.data, qp.ctypes.data, kp.ctypes.data,
                                                         dp.ctypes.data))
-            nat.check(self.lib.daam_tap_flush(self.ctx, self.stream))
+            nat.check(self.lib.daam_tap_flush(self.ctx, stream))
+            if rec_stream is not None:
+                rec_stream.wait_stream(self._current_stream())
             self._window = self.defer_steps
         finally:
             self._drop_recorded()
@@ -353,8 +412,9 @@ class HeatMapEngine:
         t, h, w = heat_map.shape
         if layer not in self.layer_info:
             raise RuntimeError('daam_amd: update() on a layer that was never tapped is not supported')
-        # clear() is lazy on the device side: make sure this layer's buffer really holds zeros / sums
-        nat.check(self.lib.daam_layer_acc(self.ctx, layer, None, None))
+        # clear() is lazy on the device side: the library zeroes the buffer now if it still owes that (on this
+        # stream) and learns that the layer holds sums again (later taps add to them, the next reset clears them)
+        nat.check(self.lib.daam_layer_touch(self.ctx, layer, self.stream))
         self.acc[layer][head] += heat_map.to(self.acc_dtype)
         self._touch(layer)
 
@@ -367,7 +427,13 @@ class HeatMapEngine:
         return out
 
     def items(self) -> Iterator[Tuple[Key, torch.Tensor]]:
+        """``((factor, layer, head), running sum [tokens, h, w])`` in first-update order.  The tensors are VIEWS of
+        the live sum buffers (no 221 MB copy per iteration); they stay valid and unchanged after ``clear()`` / the
+        end of the trace -- like the reference's tensors -- because an engine whose buffers were handed out starts its
+        next generation on fresh buffers and does not park them for reuse.  Taps of the SAME generation that follow
+        the iteration do show up in them."""
         self.flush()
+        self._views_out = True
         for layer in list(self.touched):
             factor, heads, _ = self.layer_info[layer]
             buf = self.acc[layer]

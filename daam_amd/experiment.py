@@ -47,8 +47,13 @@ class GenerationExperiment:
         return np.sum(np.array(self.image)) == 0
 
     def heat_map(self, tokenizer=None):
+        """The experiment's ``GlobalHeatMap`` (reference experiment.py:240).  A checkpoint holds the map on the CPU;
+        word maps are computed by ``libdaam_hip.so``, so the map goes (back) to the HIP device here."""
         from .heatmap import GlobalHeatMap
-        return GlobalHeatMap(self.tokenizer if tokenizer is None else tokenizer, self.prompt, self.global_heat_map)
+        maps = self.global_heat_map
+        if maps.device.type != 'cuda' and torch.cuda.is_available():
+            maps = maps.to('cuda', torch.float32).contiguous()     # without a device the word-map call fails loudly
+        return GlobalHeatMap(self.tokenizer if tokenizer is None else tokenizer, self.prompt, maps)
 
     def clear_checkpoint(self):
         (self.path / self.subtype / 'generation.pt').unlink(missing_ok=True)
@@ -67,7 +72,7 @@ class GenerationExperiment:
             self.image.save(sub / 'output.png')
         (root / 'prompt.txt').write_text(self.prompt)
         (root / 'seed.txt').write_text(str(self.seed))
-        if heat_maps and tokenizer is not None and self.global_heat_map.device.type == 'cuda':
+        if heat_maps and tokenizer is not None and (self.global_heat_map.device.type == 'cuda' or torch.cuda.is_available()):
             self.save_all_heat_maps(tokenizer)
         self.save_annotations(root)
 
@@ -95,7 +100,7 @@ class GenerationExperiment:
         for word in self.prompt.split(' '):
             try:
                 out[word] = self.save_heat_map(word, tokenizer, crop=crop)
-            except Exception:          # words the tokenizer splits differently are skipped, like the reference
+            except ValueError:         # "Search word ... not found in prompt!": skipped, like the reference (experiment.py:250-255)
                 pass
         return out
 

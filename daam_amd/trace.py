@@ -43,6 +43,9 @@ def _default_defer_bytes(pipeline=None) -> int:
     budget = 32 << 30
     try:
         dev = next(pipeline.unet.parameters()).device
+        if dev.type != 'cuda' and torch.cuda.is_available():
+            # cpu-offloaded pipelines keep their parameters on the host and run on the current device
+            dev = torch.device('cuda', torch.cuda.current_device())
         if dev.type == 'cuda':
             free, _ = torch.cuda.mem_get_info(dev)
             budget = min(budget, max(free // 4, 1 << 30))
@@ -103,8 +106,18 @@ class DiffusionHeatMapHooker(AggregateHooker):
     def layer_names(self):
         return self.locator.layer_names
 
+    def _hook_impl(self):
+        super()._hook_impl()
+        # the installed processors / patched pipeline methods see the trace through weak proxies (no reference cycle
+        # while idle); WHILE hooked they must keep it alive -- ``trace(pipe).hook()`` without holding on to the object is
+        # legal with the reference -- so the hookers pin it until unhook() breaks the cycle again
+        for member in self.module:
+            member._pinned_trace = self
+
     def _unhook_impl(self):
         super()._unhook_impl()
+        for member in self.module:
+            member._pinned_trace = None
         self.engine.flush()
 
     def to_experiment(self, path, seed=None, id='.', subtype='.', **compute_kwargs):

@@ -24,6 +24,8 @@
  *     daam_last_error() gives the message of the last failure on the calling thread.
  *   - not thread-safe per context (the reference is not re-entrant either: it serialises
  *     generation with a lock, daam/run/demo.py:69,88).
+ *   - a context belongs to the HIP device that was current at daam_ctx_create; its entry points switch to that
+ *     device for the duration of the call when another one is current.
  */
 #ifndef DAAM_HIP_H
 #define DAAM_HIP_H
@@ -35,7 +37,10 @@
 extern "C" {
 #endif
 
-#define DAAM_ABI_VERSION 1
+#define DAAM_ABI_VERSION 2
+
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#define DAAM_API __attribute__((visibility("default")))
 
 /* element types of activations (q, k, probs) and of the running sums */
 #define DAAM_F16 0
@@ -78,19 +83,23 @@ typedef struct DaamQKDesc {
  * acc_dtype = dtype of the running sums: DAAM_F16 / DAAM_BF16 reproduce the reference's fp16 / bf16
  * sums on an fp16 / bf16 pipeline bit-for-bit in the add (heatmap.py:156), DAAM_F32 is the accuracy
  * mode.  Activations must have the dtype of the sums, or the sums must be DAAM_F32. */
-int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, DaamCtx** out);
-int daam_ctx_destroy(DaamCtx* ctx);
+DAAM_API int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, DaamCtx** out);
+DAAM_API int daam_ctx_destroy(DaamCtx* ctx);
 
 /* Declare layer `layer` (= position in UNetCrossAttentionLocator.locate order, trace.py:45,50):
  * `heads` = kept batch*heads entries (BH - BH/2), `side` = sqrt(hw), `factor` =
  * int(sqrt(latent_hw // hw)) (trace.py:285).  `acc` = caller-owned zero-initialised device
  * buffer [heads, tokens, side, side] of acc_dtype, or NULL to let the library allocate it. */
-int daam_layer_configure(DaamCtx* ctx, int layer, int heads, int side, int factor, void* acc);
-int daam_layer_acc(DaamCtx* ctx, int layer, void** acc, size_t* bytes);
+DAAM_API int daam_layer_configure(DaamCtx* ctx, int layer, int heads, int side, int factor, void* acc);
+DAAM_API int daam_layer_acc(DaamCtx* ctx, int layer, void** acc, size_t* bytes);
+/* The caller is about to write into the layer's sums itself (RawHeatMapCollection.update called by hand,
+ * heatmap.py:153-156): a zeroing still owed to the buffer since the last daam_reset is enqueued on `stream` first,
+ * and the layer counts as holding sums (the next tap adds to them, the next daam_reset clears them). */
+DAAM_API int daam_layer_touch(DaamCtx* ctx, int layer, void* stream);
 
 /* RawHeatMapCollection.clear (heatmap.py:170-172; called from check_inputs, trace.py:179):
  * zero every running sum and drop any un-flushed deferred taps. */
-int daam_reset(DaamCtx* ctx, void* stream);
+DAAM_API int daam_reset(DaamCtx* ctx, void* stream);
 
 /* ---- tap -------------------------------------------------------------------------------
  * daam_tap_qk: one hooked cross-attention call, immediate: one kernel launch that
@@ -104,15 +113,15 @@ int daam_reset(DaamCtx* ctx, void* stream);
  * daam_tap_probs: same accumulate from materialised probabilities [B*H, hw, tokens]
  * (the save_heads / load_heads path, trace.py:279-282, and any processor that already
  * holds attention_probs); bit-exact with the reference in the add. */
-int daam_tap_qk(DaamCtx* ctx, int layer, const void* q, const void* k, const DaamQKDesc* d, void* stream);
-int daam_tap_qk_enqueue(DaamCtx* ctx, int layer, const void* q, const void* k, const DaamQKDesc* d);
+DAAM_API int daam_tap_qk(DaamCtx* ctx, int layer, const void* q, const void* k, const DaamQKDesc* d, void* stream);
+DAAM_API int daam_tap_qk_enqueue(DaamCtx* ctx, int layer, const void* q, const void* k, const DaamQKDesc* d);
 /* the same as n daam_tap_qk_enqueue calls in order (all or nothing): lets a host runtime that
  * records calls cheaply hand them over in one crossing of the FFI.  HOST arrays. */
-int daam_tap_qk_enqueue_many(DaamCtx* ctx, int n, const int32_t* layers, const void* const* q,
+DAAM_API int daam_tap_qk_enqueue_many(DaamCtx* ctx, int n, const int32_t* layers, const void* const* q,
                              const void* const* k, const DaamQKDesc* const* descs);
-int daam_tap_pending(DaamCtx* ctx, int* n_calls, int* max_steps);
-int daam_tap_flush(DaamCtx* ctx, void* stream);
-int daam_tap_probs(DaamCtx* ctx, int layer, const void* probs, int in_dtype, int batch_heads,
+DAAM_API int daam_tap_pending(DaamCtx* ctx, int* n_calls, int* max_steps);
+DAAM_API int daam_tap_flush(DaamCtx* ctx, void* stream);
+DAAM_API int daam_tap_probs(DaamCtx* ctx, int layer, const void* probs, int in_dtype, int batch_heads,
                    int hw, int tokens, void* stream);
 
 /* ---- finalize ---------------------------------------------------------------------------
@@ -121,12 +130,12 @@ int daam_tap_probs(DaamCtx* ctx, int layer, const void* probs, int in_dtype, int
  * `heads` (offset of layer l = sum of heads of layers < l, see daam_key_offset), non-zero =
  * selected.  NULL selects every key.  Writes out[tokens, out_side, out_side] fp32 =
  * mean over selected keys of clamp(bicubic(sum_plane), 0).  `out` is overwritten. */
-int daam_key_offset(DaamCtx* ctx, int layer, int* offset, int* total);
-int daam_finalize(DaamCtx* ctx, const uint8_t* key_mask, float* out, void* stream);
+DAAM_API int daam_key_offset(DaamCtx* ctx, int layer, int* offset, int* total);
+DAAM_API int daam_finalize(DaamCtx* ctx, const uint8_t* key_mask, float* out, void* stream);
 
 /* trace.py:129-130: maps[:n_rows] / (maps[1:n_rows-1].sum(0) + 1e-6), in place on the first
  * n_rows planes of `maps` [*, side, side] fp32. */
-int daam_epilogue_normalize(float* maps, int n_rows, int side, void* stream);
+DAAM_API int daam_epilogue_normalize(float* maps, int n_rows, int side, void* stream);
 
 /* ---- word maps (next row f1) -------------------------------------------------------------
  * heatmap.py:121-123 + 77-93: mean of the planes `idx[0..n_idx)` (HOST int array) of
@@ -134,21 +143,21 @@ int daam_epilogue_normalize(float* maps, int n_rows, int side, void* stream);
  * eps 1e-8) -> (threshold != 0 ? (x > threshold) : x).  word_map[side*side] (required) receives
  * the un-expanded mean plane; `out` [out_h, out_w] fp32 (NULL: only the mean plane is computed);
  * `workspace` >= 2 floats of device scratch for the min/max. */
-int daam_word_heat_map(const float* maps, int side, const int32_t* idx, int n_idx, float* word_map,
+DAAM_API int daam_word_heat_map(const float* maps, int side, const int32_t* idx, int n_idx, float* word_map,
                        float* out, int out_h, int out_w, int absolute, float threshold,
                        float* workspace, void* stream);
 
 /* ---- misc -------------------------------------------------------------------------------- */
-int daam_abi_version(void);
-const char* daam_last_error(void);
+DAAM_API int daam_abi_version(void);
+DAAM_API const char* daam_last_error(void);
 /* per-kernel launch statistics of the last tap / finalize launch (for bench.py):
  * grid size and dynamic LDS bytes; 0 if nothing launched yet. */
-int daam_last_launch(DaamCtx* ctx, int which /*0 tap,1 finalize*/, int* grid, int* block, int* lds_bytes);
+DAAM_API int daam_last_launch(DaamCtx* ctx, int which /*0 tap,1 finalize*/, int* grid, int* block, int* lds_bytes);
 /* kernel timing for bench.py: when enabled, every tap / finalize call brackets ITS KERNEL LAUNCHES (not
  * the table upload before them) with HIP events on the call's stream; daam_profile_last_ms waits for the
  * last pair and returns the elapsed milliseconds (the only other call that synchronises the host). */
-int daam_profile_enable(DaamCtx* ctx, int on);
-int daam_profile_last_ms(DaamCtx* ctx, int which /*0 tap,1 finalize*/, float* ms);
+DAAM_API int daam_profile_enable(DaamCtx* ctx, int on);
+DAAM_API int daam_profile_last_ms(DaamCtx* ctx, int which /*0 tap,1 finalize*/, float* ms);
 
 #ifdef __cplusplus
 }

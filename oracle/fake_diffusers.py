@@ -78,10 +78,25 @@ class FakeAttention(nn.Module):
         return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
                               attention_mask=attention_mask, **kw)
 
-    def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size=None, out_dim=3):
+        """diffusers 0.21.2 ``Attention.prepare_attention_mask``: ``None`` passes through; a mask whose last dim
+        differs from ``target_length`` is padded by ``target_length`` zeros (sic); then repeated per head.  The
+        reference passes the QUERY length as ``target_length`` (trace.py:259-260), so a ``[B, 1, 77]`` cross-attention
+        bias is padded to ``77 + hw`` columns and ``baddbmm`` then fails -- a masked cross-attention call is an
+        error in the reference unless the mask is already ``hw`` columns wide."""
+        head_size = self.heads
         if attention_mask is None:
-            return None
-        raise NotImplementedError('SD / SDXL cross-attention passes no mask')
+            return attention_mask
+        current_length = attention_mask.shape[-1]
+        if current_length != target_length:
+            attention_mask = torch.nn.functional.pad(attention_mask, (0, target_length), value=0.0)
+        if out_dim == 3:
+            if attention_mask.shape[0] < batch_size * head_size:
+                attention_mask = attention_mask.repeat_interleave(head_size, dim=0)
+        elif out_dim == 4:
+            attention_mask = attention_mask.unsqueeze(1)
+            attention_mask = attention_mask.repeat_interleave(head_size, dim=1)
+        return attention_mask
 
     def head_to_batch_dim(self, t):
         b, s, c = t.shape
@@ -190,7 +205,8 @@ class FakeUNet(nn.Module):
 
     def __init__(self, kind: str, *, sample_size: Optional[int] = None, mini: bool = True,
                  identity_proj: bool = True, heads_scale: float = 1.0, tblocks_cap: Optional[int] = None,
-                 dim_head: Optional[int] = None, latent_size: Optional[int] = None):
+                 dim_head: Optional[int] = None, latent_size: Optional[int] = None,
+                 upcast_attention: bool = False, upcast_softmax: bool = False):
         super().__init__()
         self.kind = kind
         if kind == 'sd15':
@@ -229,11 +245,12 @@ class FakeUNet(nn.Module):
         def make_factory(level):
             h, d = level_params(level)
             inner = h * d
+            flags = dict(upcast_attention=upcast_attention, upcast_softmax=upcast_softmax)
             if identity_proj:
-                return lambda: FakeAttention(inner, inner, h, d, identity_proj=True)
+                return lambda: FakeAttention(inner, inner, h, d, identity_proj=True, **flags)
             qd = inner if mini else chans[level]
             cd = inner if mini else cross_dim
-            return lambda: FakeAttention(qd, cd, h, d)
+            return lambda: FakeAttention(qd, cd, h, d, **flags)
 
         def cap(n):
             return n if tblocks_cap is None else min(n, tblocks_cap)
@@ -278,14 +295,18 @@ class FakeUNet(nn.Module):
                     out.append(LayerSpec(a, blk.res, a.heads, a.dim_head, qd))
         return out
 
-    def forward(self, hidden_fn, context_fn, step: int):
+    def forward(self, hidden_fn, context_fn, step: int, mask_fn=None):
         """``hidden_fn(spec_index, spec, step) -> [B, res*res, query_dim]`` and
-        ``context_fn(spec_index, spec) -> [B, 77, cross_dim_of_layer]``."""
+        ``context_fn(spec_index, spec) -> [B, 77, cross_dim_of_layer]``; optional
+        ``mask_fn(spec_index, spec) -> attention_mask`` (stock SD / SDXL pipelines pass none)."""
         outs = []
         for i, spec in enumerate(self.execution_order()):
             hs = hidden_fn(i, spec, step)
             ctx = context_fn(i, spec)
-            outs.append(spec.module(hs, encoder_hidden_states=ctx))
+            if mask_fn is None:
+                outs.append(spec.module(hs, encoder_hidden_states=ctx))
+            else:
+                outs.append(spec.module(hs, encoder_hidden_states=ctx, attention_mask=mask_fn(i, spec)))
         return outs
 
 
@@ -329,6 +350,9 @@ class _PipeBase:
         self.sos_gain = sos_gain
         self.seed = 0
         self.checked = []
+        self.mask_fn = None           # optional: (i, spec) -> attention_mask for every cross-attention call
+        self.keep_outputs = False     # True: ``last_outputs`` = what every attn2 returned in the final step
+        self.last_outputs = None
 
     # patched by PipelineHooker (trace.py:171-186)
     def check_inputs(self, prompt, *args, **kwargs):
@@ -359,7 +383,9 @@ class _PipeBase:
         self.check_inputs(prompt, 512, 512, 1)
         with torch.no_grad():
             for step in range(num_inference_steps):
-                self.unet(self.hidden_states, self.context, step)
+                outs = self.unet(self.hidden_states, self.context, step, self.mask_fn)
+                if self.keep_outputs and step == num_inference_steps - 1:
+                    self.last_outputs = outs
                 if callback is not None:
                     callback(step, step, None)
         image = 'image-of:' + (prompt if isinstance(prompt, str) else prompt[0])
@@ -389,7 +415,15 @@ class DiffusionPipeline(_PipeBase):
 
 
 def make_pipe(kind: str, *, device='cpu', dtype=torch.float32, batch=2, seed=0, **unet_kw):
-    unet = FakeUNet(kind, **unet_kw).to(device=device, dtype=dtype)
+    # the to_v / to_out weights (the only random parameters; they do not influence any heat map) are drawn on the
+    # CPU from a generator state fixed by ``seed``, so the processors' outputs are reproducible bit for bit
+    rng_state = torch.get_rng_state()
+    torch.manual_seed(1000 + seed)
+    try:
+        unet = FakeUNet(kind, **unet_kw)
+    finally:
+        torch.set_rng_state(rng_state)
+    unet = unet.to(device=device, dtype=dtype)
     cls = StableDiffusionXLPipeline if kind == 'sdxl' else StableDiffusionPipeline
     pipe = cls(unet, device=device, dtype=dtype, batch=batch)
     pipe.seed = seed

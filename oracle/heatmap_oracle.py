@@ -58,12 +58,16 @@ def _cast(x: np.ndarray, dt) -> np.ndarray:
 # --------------------------------------------------------------------------------------
 # K1 / K2: diffusers Attention.get_attention_scores as called at trace.py:276
 # --------------------------------------------------------------------------------------
-def attention_probs(q: np.ndarray, k: np.ndarray, scale: float, pipe_dtype=np.float32) -> np.ndarray:
+def attention_probs(q: np.ndarray, k: np.ndarray, scale: float, pipe_dtype=np.float32,
+                    upcast_attention: bool = False, mask: Optional[np.ndarray] = None) -> np.ndarray:
     """``softmax(scale * q k^T, -1)`` with the reference pipeline's rounding points.
 
     q ``[BH, hw, d]``, k ``[BH, T, d]`` -> probs ``[BH, hw, T]`` in ``pipe_dtype``.
     (diffusers 0.21.2 ``get_attention_scores``: ``baddbmm(beta=0, alpha=scale)`` ->
-    ``softmax(dim=-1)`` -> ``.to(dtype)``; SURVEY Appendix A.)
+    ``softmax(dim=-1)`` -> ``.to(dtype)``; SURVEY Appendix A.)  ``upcast_attention``: q, k are up-cast first, so
+    the logits stay f32 (no rounding to the pipeline dtype).  ``upcast_softmax`` changes nothing numerically: the
+    softmax of fp16 logits already runs in f32 internally.  ``mask``: additive bias ``[BH, 1 | hw, T]``
+    (``baddbmm(mask, q, k^T, beta=1)``: added in f32 before the rounding).
     """
     if not is_bf16(pipe_dtype):
         pipe_dtype = np.dtype(pipe_dtype)
@@ -74,7 +78,10 @@ def attention_probs(q: np.ndarray, k: np.ndarray, scale: float, pipe_dtype=np.fl
         return e / e.sum(-1, keepdims=True)
     # fp32 accumulate, alpha applied in fp32, result rounded to the pipe dtype
     acc = np.matmul(q.astype(np.float32), np.swapaxes(k.astype(np.float32), -1, -2))
-    logits = _cast(acc * np.float32(scale), pipe_dtype)
+    acc = acc * np.float32(scale)
+    if mask is not None:
+        acc = acc + mask.astype(np.float32)
+    logits = acc if upcast_attention else _cast(acc, pipe_dtype)
     x = logits.astype(np.float32)
     m = x.max(-1, keepdims=True)
     e = np.exp(x - m, dtype=np.float32)
@@ -139,11 +146,11 @@ class RawMaps:
 
 def tap(raw: RawMaps, layer_idx: int, q: np.ndarray, k: np.ndarray, scale: float,
         latent_hw: int, pipe_dtype=np.float32, context_size: int = 77,
-        probs: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
+        probs: Optional[np.ndarray] = None, upcast_attention: bool = False) -> Optional[np.ndarray]:
     """One hooked cross-attention call (trace.py:276-294): scores -> gate -> unravel ->
     per-head update.  Returns the probabilities (the reference needs them for ``bmm``)."""
     if probs is None:
-        probs = attention_probs(q, k, scale, pipe_dtype)
+        probs = attention_probs(q, k, scale, pipe_dtype, upcast_attention)
     factor = layer_factor(latent_hw, probs.shape[1])
     if probs.shape[-1] == context_size and factor != 8:          # trace.py:289
         maps = unravel(probs)
@@ -312,5 +319,5 @@ def replay_generation(pipe, steps: int, pipe_dtype, acc_dtype=None, restrict=Non
             a = spec.module
             q = as_np(a.head_to_batch_dim(a.to_q(pipe.hidden_states(i, spec, step))))
             k = as_np(a.head_to_batch_dim(a.to_k(pipe.context(i, spec))))
-            tap(raw, li, q, k, a.scale, lat, np_dtype)
+            tap(raw, li, q, k, a.scale, lat, np_dtype, upcast_attention=getattr(a, 'upcast_attention', False))
     return raw

@@ -64,9 +64,25 @@ CASES = {
                            unet=dict(dim_head=8)),
     'sd15_b4_f32': dict(kind='sd15', dtype='float32', batch=4, steps=2, prompt='a dog', seed=17,
                         unet=dict(dim_head=8, heads_scale=0.25)),
+    # save_heads=True: the ONLY configuration in which the locator also returns the mid block (trace.py:34-35).
+    # SDXL: the mid block (32x32 at 1024 px) is captured with factor 2; SD-v1.5: located, but its 8x8 maps hit the
+    # ``factor != 8`` gate (trace.py:289).  Every processor call writes ``{gen_idx}.pt`` (trace.py:246-247); a second
+    # trace with load_heads=True on a pipeline fed DIFFERENT hidden states replays those files (trace.py:281-282).
+    'sdxl_heads_f32': dict(kind='sdxl', dtype='float32', batch=2, steps=2, prompt='a photo of a monkey', seed=19,
+                           unet=dict(dim_head=8, heads_scale=0.2, tblocks_cap=1), heads=True,
+                           variants=['default', 'normalize', 'layer']),
+    'sd15_heads_f16': dict(kind='sd15', dtype='float16', batch=2, steps=3, prompt='a dog', seed=20,
+                           unet=dict(dim_head=16), heads=True, variants=['default', 'factor_hi']),
+    # Attention flags of other checkpoints (SD-2.1-768 sets upcast_attention): f32 logits straight into the softmax /
+    # softmax on up-cast fp16 logits (diffusers get_attention_scores)
+    'sd15_upcast_attn_f16': dict(kind='sd15', dtype='float16', batch=2, steps=4, prompt='a dog', seed=21,
+                                 unet=dict(dim_head=16, upcast_attention=True), variants=['default', 'normalize']),
+    'sd15_upcast_softmax_f16': dict(kind='sd15', dtype='float16', batch=2, steps=4, prompt='a dog', seed=22,
+                                    unet=dict(dim_head=16, upcast_softmax=True), variants=['default']),
 }
 
 SAMPLE_TOKENS = [0, 1, 2, 76]
+OUT_SAMPLE_ROWS = 6          # rows of each processor output kept verbatim in the fixture
 
 
 def input_checksums(pipe, steps):
@@ -81,13 +97,45 @@ def input_checksums(pipe, steps):
     return np.asarray(s, dtype=np.float64)
 
 
+def output_fingerprint(pipe):
+    """What every cross-attention processor call returned in the last step (reference trace.py:304), execution
+    order: ``[n, 2]`` float64 (sum, sum of squares) + the first rows of batch element 1 verbatim."""
+    outs = pipe.last_outputs
+    sums = np.asarray([[float(o.double().sum()), float((o.double() ** 2).sum())] for o in outs])
+    rows = [o[-1, :OUT_SAMPLE_ROWS].float().numpy() for o in outs]
+    return sums, rows
+
+
+def heads_fingerprint(data_dir, n_files):
+    """``{gen_idx}.pt`` files written by save_heads (trace.py:246-247): shape, dtype, (sum, sum of squares)."""
+    shapes, stats, dtypes = [], [], []
+    for i in range(n_files):
+        t = torch.load(os.path.join(data_dir, f'{i}.pt'))
+        shapes.append(list(t.shape))
+        dtypes.append(str(t.dtype))
+        stats.append([float(t.double().sum()), float((t.double() ** 2).sum())])
+    return np.asarray(shapes, dtype=np.int64), np.asarray(stats), dtypes
+
+
 def run_case(name, spec, daam):
+    import tempfile
     dtype = getattr(torch, spec['dtype'])
     pipe = fd.make_pipe(spec['kind'], dtype=dtype, batch=spec['batch'], seed=spec['seed'],
                         mini=True, identity_proj=True, **spec['unet'])
+    pipe.keep_outputs = True
     out = {}
-    with daam.trace(pipe) as tc:
+    heads_dir = tempfile.mkdtemp(prefix='daam_heads_') if spec.get('heads') else None
+    trace_kw = dict(save_heads=True, data_dir=heads_dir) if heads_dir else {}
+    with daam.trace(pipe, **trace_kw) as tc:
         pipe(spec['prompt'], num_inference_steps=spec['steps'], callback=tc.time_callback)
+        out['out_sums'], rows = output_fingerprint(pipe)
+        for i, r in enumerate(rows):
+            out[f'out_rows_{i}'] = r
+        if heads_dir:
+            n_files = tc._gen_idx
+            out['heads_n_files'] = np.asarray(n_files)
+            out['heads_shapes'], out['heads_stats'], hd = heads_fingerprint(heads_dir, n_files)
+            out['heads_dtypes'] = np.asarray(json.dumps(hd))
         items = list(tc.all_heat_maps)
         keys = np.asarray([k for k, _ in items], dtype=np.int32)
         out['keys'] = keys
@@ -140,6 +188,22 @@ def run_case(name, spec, daam):
         out['last_prompt'] = np.asarray(tc.last_prompt)
         out['last_image'] = np.asarray(str(tc.last_image))
         out['time_idx'] = np.asarray(tc.time_idx)
+    if heads_dir:
+        # replay: a pipeline with OTHER hidden states (seed + 100) under load_heads=True reads the saved probabilities
+        # back, so its maps equal the ones above and its attention outputs are the saved probabilities x its own V
+        pipe2 = fd.make_pipe(spec['kind'], dtype=dtype, batch=spec['batch'], seed=spec['seed'] + 100,
+                             mini=True, identity_proj=True, **spec['unet'])
+        pipe2.keep_outputs = True
+        with daam.trace(pipe2, load_heads=True, data_dir=heads_dir) as tc2:
+            pipe2(spec['prompt'], num_inference_steps=spec['steps'])
+            hm = tc2.all_heat_maps.ids_to_heatmaps
+            if dtype in (torch.float16, torch.bfloat16):
+                for k in list(hm.keys()):
+                    hm[k] = hm[k].float()
+            out['global_replay'] = tc2.compute_global_heat_map().heat_maps.float().numpy()
+            out['replay_out_sums'], rows = output_fingerprint(pipe2)
+        import shutil
+        shutil.rmtree(heads_dir, ignore_errors=True)
     out['input_checksums'] = input_checksums(pipe, spec['steps'])
     meta = dict(spec)
     meta['reference'] = 'castorini/daam v0.2.0, executed unmodified via oracle/fake_diffusers.py'

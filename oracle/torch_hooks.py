@@ -61,6 +61,34 @@ def tap(raw: RawMaps, layer_idx: int, probs: torch.Tensor, latent_hw: int, conte
             raw.update(factor, layer_idx, head_idx, heat_map)
 
 
+class ReferenceProcessor:
+    """The reference's attention processor (``UNetCrossAttentionHooker.__call__``, trace.py:252-304) as a plain
+    torch op sequence: mask preparation with the QUERY length, optional ``norm_cross``, materialised probabilities from
+    ``attn.get_attention_scores``, the DAAM tap (``tap`` above), ``bmm`` and the output projection.  ``raw=None``
+    skips the tap (then it is what a stock materialising processor computes)."""
+
+    def __init__(self, raw: Optional['RawMaps'] = None, layer_idx: int = 0, latent_hw: int = 4096):
+        self.raw, self.layer_idx, self.latent_hw = raw, layer_idx, latent_hw
+
+    @torch.no_grad()
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, **_):
+        batch_size, sequence_length, _c = hidden_states.shape
+        attention_mask = attn.prepare_attention_mask(attention_mask, sequence_length, batch_size)   # trace.py:259-260
+        query = attn.to_q(hidden_states)
+        if encoder_hidden_states is None:
+            encoder_hidden_states = hidden_states
+        elif attn.norm_cross is not None:
+            encoder_hidden_states = attn.norm_cross(encoder_hidden_states)                         # trace.py:264-267
+        key = attn.head_to_batch_dim(attn.to_k(encoder_hidden_states))
+        value = attn.head_to_batch_dim(attn.to_v(encoder_hidden_states))
+        query = attn.head_to_batch_dim(query)
+        probs = attn.get_attention_scores(query, key, attention_mask)                              # trace.py:276
+        if self.raw is not None:
+            tap(self.raw, self.layer_idx, probs, self.latent_hw)                                    # trace.py:285-294
+        out = attn.batch_to_head_dim(torch.bmm(probs, value))                                      # trace.py:296-297
+        return attn.to_out[1](attn.to_out[0](out))                                                 # trace.py:300-302
+
+
 @torch.no_grad()
 def attention_probs(q: torch.Tensor, k: torch.Tensor, scale: float) -> torch.Tensor:
     """diffusers 0.21.2 get_attention_scores (no mask, no upcast) as called at trace.py:276."""

@@ -20,7 +20,7 @@ import torch
 
 from conftest import GOLDEN_CASES, golden_pipe, load_golden
 from oracle import heatmap_oracle as ho
-from oracle.make_golden import SAMPLE_TOKENS
+from oracle.make_golden import OUT_SAMPLE_ROWS, SAMPLE_TOKENS
 
 pytestmark = pytest.mark.gpu
 
@@ -265,13 +265,40 @@ def _global_tol(meta):
     return {'float32': 2e-6, 'float16': 1e-3, 'bfloat16': 8e-3}[meta['dtype']]
 
 
+def _out_tol(meta):
+    # processor outputs (trace.py:296-304), relative to the largest |value| of the compared rows: fp32 = summation
+    # order of the GEMMs; fp16 / bf16 = the fused route keeps the probabilities in f32 up to P.V where the reference
+    # rounds them to the pipeline dtype first, plus the output rounding
+    return {'float32': 1e-5, 'float16': 2e-3, 'bfloat16': 1.6e-2}[meta['dtype']]
+
+
+def _check_processor_outputs(pipe, z, meta, sums_key='out_sums', rows=True):
+    """``hidden_states`` returned by every hooked / un-hooked cross-attention call of the last step against what the
+    REFERENCE's processor returned (fixtures: per-call sum of squares + the first rows of the conditional batch)."""
+    outs = pipe.last_outputs
+    assert len(outs) == len(z[sums_key])
+    rel = _out_tol(meta)
+    for i, o in enumerate(outs):
+        sq = float((o.double() ** 2).sum())
+        assert abs(sq - z[sums_key][i, 1]) <= 4 * rel * z[sums_key][i, 1], f'call {i}: sum of squares'
+        if rows:
+            want = z[f'out_rows_{i}']
+            got = o[-1, :OUT_SAMPLE_ROWS].float().cpu().numpy()
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= rel * max(float(np.abs(want).max()), 1e-6), f'call {i}: rows'
+
+
 @pytest.mark.parametrize('tap,defer', [('qk', 0), ('qk', 2), ('qk', 50), ('probs', 0)])
-def test_trace_api_matches_reference_golden(golden_case, tap, defer):
+def test_trace_api_matches_reference_golden(golden_case, tap, defer, tmp_path):
     import daam_amd
     name, z, meta = golden_case
     pipe = golden_pipe(meta, device=DEV)
-    with daam_amd.trace(pipe, tap=tap, defer_steps=defer) as tc:
+    pipe.keep_outputs = True
+    # the save_heads cases: the locator also returns the mid block and every call goes through the materialised route
+    trace_kw = dict(save_heads=True, data_dir=str(tmp_path)) if meta.get('heads') else {}
+    with daam_amd.trace(pipe, tap=tap, defer_steps=defer, **trace_kw) as tc:
         out = pipe(meta['prompt'], num_inference_steps=meta['steps'], callback=tc.time_callback)
+        _check_processor_outputs(pipe, z, meta)
         items = list(tc.all_heat_maps)
         keys = np.asarray([k for k, _ in items], dtype=np.int32)
         np.testing.assert_array_equal(keys, z['keys'])              # same keys, same first-update order
@@ -308,7 +335,30 @@ def test_trace_api_matches_reference_golden(golden_case, tap, defer):
         assert tc.last_prompt == str(z['last_prompt'])
         assert str(tc.last_image) == str(z['last_image'])
         assert int(tc.time_idx) == int(z['time_idx'])
+        if meta.get('heads'):
+            assert tc._gen_idx == int(z['heads_n_files'])
     assert out.images
+    if not meta.get('heads'):
+        return
+    # ---- heads cache: one ``{gen_idx}.pt`` per processor call with the probabilities [B*H, hw, 77] (trace.py:246-247)
+    n_files = int(z['heads_n_files'])
+    dtypes = json.loads(str(z['heads_dtypes']))
+    rtol = {'float32': 1e-5, 'float16': 1e-3}[meta['dtype']]
+    for i in range(n_files):
+        t = torch.load(tmp_path / f'{i}.pt')
+        assert list(t.shape) == z['heads_shapes'][i].tolist() and str(t.dtype) == dtypes[i]
+        np.testing.assert_allclose([float(t.double().sum()), float((t.double() ** 2).sum())], z['heads_stats'][i], rtol=rtol)
+    assert not (tmp_path / f'{n_files}.pt').exists()
+    # ---- replay (trace.py:281-282): another pipeline (other hidden states, other V) under load_heads=True reads the
+    # saved probabilities back -> the same maps, and attention outputs = saved probabilities x ITS values
+    pipe2 = golden_pipe(meta, device=DEV, seed_offset=100)
+    pipe2.keep_outputs = True
+    with daam_amd.trace(pipe2, load_heads=True, data_dir=str(tmp_path), tap=tap, defer_steps=defer) as tc2:
+        pipe2(meta['prompt'], num_inference_steps=meta['steps'])
+        got = tc2.compute_global_heat_map().heat_maps.cpu().numpy()
+        np.testing.assert_allclose(got, z['global_replay'], rtol=0,
+                                   atol=_global_tol(meta) * max(1.0, float(np.abs(z['global_replay']).max())))
+        _check_processor_outputs(pipe2, z, meta, sums_key='replay_out_sums', rows=False)
 
 
 @pytest.mark.parametrize('env', [dict(DAAM_STRICT_EXP='1'), dict(DAAM_NO_D64='1'), dict(DAAM_NO_D64='1', DAAM_STRICT_EXP='1'),
@@ -512,3 +562,11 @@ def test_to_experiment_and_plot(tmp_path):
     back = daam_amd.GenerationExperiment.load(root, subtype='run')
     # two finalize calls: the f32 atomics may add the keys in a different order
     assert torch.allclose(back.global_heat_map, ghm.heat_maps.cpu(), rtol=0, atol=1e-6)
+    # a LOADED experiment (map on the CPU) still yields word maps and overlay files, like the reference's
+    assert back.global_heat_map.device.type == 'cpu'
+    whm = back.heat_map().compute_word_heat_map('dog')
+    assert torch.allclose(whm.heatmap.cpu(), ghm.compute_word_heat_map('dog').heatmap.cpu(), rtol=0, atol=1e-6)
+    (root / 'run' / 'dog.heat_map.png').unlink()
+    saved = back.save_all_heat_maps()
+    assert set(saved) == {'a', 'dog'} and all(p.exists() for p in saved.values())
+

@@ -34,8 +34,14 @@ def test_library_exports_every_declared_symbol():
     assert declared == sorted(_native.EXPORTS), 'include/daam_hip.h and daam_amd/_native.py disagree'
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.daam_abi_version() == 1
+    assert lib.daam_abi_version() == 2
     assert ctypes.sizeof(_native.QKDesc) == 80          # 8 x 4 bytes + 6 x 8 bytes, no padding surprises
+    # built with -fvisibility=hidden: the only FUNCTIONS the library exports are the C ABI (the remaining dynamic
+    # symbols are the device-kernel handles the HIP runtime registers)
+    import subprocess
+    nm = subprocess.run(['nm', '-D', '--defined-only', _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    functions = sorted(line.split()[-1] for line in nm.splitlines() if line.split()[-2] in ('T', 't'))
+    assert functions == declared, set(functions) ^ set(declared)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
@@ -106,7 +112,7 @@ def test_layer_names_match_reference_golden(golden_case):
     from daam_amd.hook import UNetCrossAttentionLocator
     name, z, meta = golden_case
     pipe = golden_pipe(meta)
-    loc = UNetCrossAttentionLocator()
+    loc = UNetCrossAttentionLocator(locate_middle_block=bool(meta.get('heads')))        # trace.py:34-35
     loc.locate(pipe.unet)
     assert loc.layer_names == json.loads(str(z['layer_names']))
 
@@ -187,7 +193,19 @@ def fake_engine(monkeypatch):
     monkeypatch.setattr(E.nat, 'load', lambda: lib)
     monkeypatch.setattr(E.HeatMapEngine, '_require_device',
                         lambda self, t: setattr(self, 'device', torch.device('cpu')))
-    monkeypatch.setattr(E.HeatMapEngine, 'stream', property(lambda self: 0))
+    class _Stream:
+        cuda_stream = 0
+
+        def wait_stream(self, other):
+            pass
+
+        def wait_event(self, ev):
+            pass
+
+        def record_event(self):
+            return object()
+    one = _Stream()
+    monkeypatch.setattr(E.HeatMapEngine, '_current_stream', lambda self: one)
     monkeypatch.setattr(torch.cuda, 'device', lambda d: __import__('contextlib').nullcontext())
     return E, lib
 
@@ -373,6 +391,13 @@ def test_defer_budget_defaults(monkeypatch):
     monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda dev: (1 << 30, 288 << 30))
     assert T._default_defer_bytes(_Pipe()) == 1 << 30
     assert T._default_defer_bytes(object()) == 32 << 30            # no parameters to ask: the default
+    # cpu-offloaded pipeline: parameters on the host, work on the current HIP device -> that device's free memory counts
+    _P.device = torch.device('cpu')
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: 0)
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda dev: (8 << 30, 288 << 30))
+    assert T._default_defer_bytes(_Pipe()) == 2 << 30
+    _P.device = torch.device('cuda', 0)
     monkeypatch.setenv('DAAM_DEFER_BYTES', str(5 << 30))
     assert T._default_defer_bytes(_Pipe()) == 5 << 30
     monkeypatch.setenv('DAAM_DEFER_STEPS', '7')

@@ -23,7 +23,7 @@ def test_oracle_matches_reference(golden_case):
     np.testing.assert_allclose(input_checksums(pipe, meta['steps']), z['input_checksums'], rtol=0, atol=0)
     import torch
     dt = getattr(torch, meta['dtype'])
-    raw = ho.replay_generation(pipe, meta['steps'], dt)
+    raw = ho.replay_generation(pipe, meta['steps'], dt, locate_middle_block=bool(meta.get('heads')))
     keys = np.asarray([k for k, _ in raw], dtype=np.int32)
     np.testing.assert_array_equal(keys, z['keys'])          # same keys, same insertion order
     sums = np.asarray([float(v.astype(np.float64).sum()) for _, v in raw])
