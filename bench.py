@@ -19,9 +19,15 @@ Multi-GPU: generations are independent (the reference is single-prompt by constr
 daam/trace.py:172-173): rank r runs its own K generations; the only exchange is one RCCL
 all_gather of the final maps, inside the timed region.  ``scaling`` = weak.
 
+``python bench.py --gpus N`` outside a launcher re-executes itself under ``torch.distributed.run`` with N ranks (one per
+GPU); it never reports ``n_gpus`` other than the N it was asked for.
+
 The one JSON line also carries ``roofline`` (tap kernel: algorithmic bytes / HIP-event time of the launch
-as it occurs in the timed region) and ``cpu_baseline`` (the torch port of the reference's hook path,
-oracle/torch_hooks.py, timed on the host cores on a bounded sample).
+as it occurs in the timed region), ``roofline_issue`` (the same launch against its instruction-issue floor: VALU busy
+cycles from the committed PMC pass of this build + the MFMA issue cost, at the shader clock sampled IN this run while
+the kernel executes), ``roofline_finalize`` / ``roofline_finalize_issue``, ``integrated`` (extraction overhead per
+denoising step inside a full-size synthetic SDXL cross-attention stack, tools/synthetic_unet.py) and ``cpu_baseline``
+(the torch port of the reference's hook path, oracle/torch_hooks.py, timed on the host cores on a bounded sample).
 """
 from __future__ import annotations
 
@@ -99,6 +105,29 @@ def tap_bytes(layers, steps_per_launch, acc_bytes, fresh):
     return steps_per_launch * qk + acc * (1 if fresh else 2), qk, acc
 
 
+class ClockMonitor:
+    """Shader clock while the kernels under test run (daam_clock_monitor_*: one wave samples the cycle counter against
+    the 100 MHz reference counter every 100 us on its own stream)."""
+
+    def __init__(self, eng, window_ms=60.0, period_us=100):
+        from daam_amd import _native as nat
+        self.nat, self.eng = nat, eng
+        self.n = max(8, min(4096, int(window_ms * 1e3 / period_us)))
+        nat.check(eng.lib.daam_clock_monitor_start(eng.ctx, self.n, period_us))
+
+    def read(self):
+        import ctypes
+        buf = (ctypes.c_float * self.n)()
+        n = ctypes.c_int()
+        self.nat.check(self.eng.lib.daam_clock_monitor_read(self.eng.ctx, buf, self.n, ctypes.byref(n)))
+        v = sorted(buf[i] for i in range(n.value))
+        if not v:
+            return None
+        busy = v[: max(1, len(v) // 2)]            # the lower half: intervals in which the kernels were running (idle gaps clock up)
+        return dict(mhz_median_under_load=round(busy[len(busy) // 2], 1), mhz_min=round(v[0], 1), mhz_max=round(v[-1], 1),
+                    samples=len(v), method='s_memtime / s_memrealtime, 100 us intervals, concurrent one-wave monitor kernel')
+
+
 def measure_tap_kernel(eng, calls, defer, reps, fresh):
     """HIP-event time of the tap kernel: libdaam_hip brackets its kernel launch(es) with events on
     the launch stream (daam_profile_enable), the table upload in front of them is outside.
@@ -142,6 +171,50 @@ def measure_finalize(eng, reps):
     return sum(times) / len(times)
 
 
+def cpu_model() -> str:
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _one_thread_baseline(th, layers, denoise_steps):
+    """The same port on ONE host thread, on a sample a tenth the size: every 10th hooked layer for one
+    denoising step and compute_global_heat_map over those layers' keys, scaled by the work ratio."""
+    import torch as _t
+    prev = _t.get_num_threads()
+    _t.set_num_threads(1)
+    try:
+        sub = layers[::10]
+        raw = th.RawMaps()
+        probs = {}
+        t0 = time.perf_counter()
+        for (layer, heads, side, d) in sub:
+            key = (heads, side)
+            if key not in probs:
+                probs[key] = _t.rand(2 * heads, side * side, 77)
+        t_gen = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for (layer, heads, side, d) in sub:
+            th.tap(raw, layer, probs[(heads, side)], 4096)
+        t_tap = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        th.global_heat_map(raw, 4096)
+        t_fin = time.perf_counter() - t0
+    finally:
+        _t.set_num_threads(prev)
+    elems_all = sum(h * s * s for _, h, s, _ in layers)
+    elems_sub = sum(h * s * s for _, h, s, _ in sub)
+    ratio = elems_all / elems_sub
+    per_step, fin = t_tap * ratio, t_fin * ratio
+    return dict(value=round(1.0 / (per_step * denoise_steps + fin), 6), unit='maps/s', cores=1,
+                ms_per_denoise_step=round(per_step * 1e3, 2), finalize_s=round(fin, 3),
+                sample=f'{len(sub)} of {len(layers)} layers x 1 step + finalize of their {len(raw)} keys, scaled x{ratio:.1f} by element count')
+
+
 def cpu_baseline(kind, latent, denoise_steps, sample_steps=2, eager_device=None):
     """THE baseline leg (the only place bench.py touches oracle/, and only to time it): the reference's hook
     path (torch port, oracle/torch_hooks.py) on the host cores, fp32 (the reference's CPU-runnable
@@ -169,7 +242,8 @@ def cpu_baseline(kind, latent, denoise_steps, sample_steps=2, eager_device=None)
     t_fin = time.perf_counter() - t0
     per_step = t_tap / sample_steps
     total = per_step * denoise_steps + t_fin
-    out = dict(value=1.0 / total, unit='maps/s', cores=cores, kind='port',
+    out = dict(value=1.0 / total, unit='maps/s', cores=cores, kind='port', cpu=cpu_model(),
+               one_thread=_one_thread_baseline(th, layers, denoise_steps),
                ms_per_denoise_step=per_step * 1e3, finalize_s=t_fin,
                sample=f'{sample_steps} denoising steps x {len(layers)} layers of _unravel_attn+update (fp32, torch '
                       f'{torch.__version__}, {cores} threads) + 1 compute_global_heat_map over {len(raw)} keys; '
@@ -204,6 +278,69 @@ def _port_eager_on_device(th, kind, latent, denoise_steps, device, sample_steps=
                 maps_per_s=1.0 / (per_step * denoise_steps + t_fin))
 
 
+def integrated_overhead(device, steps=20, reps=3):
+    """Extraction overhead per denoising step INSIDE a model-shaped stack (metric (i), integrated harness):
+    step time of a full-size synthetic SDXL-1024 cross-attention stack (70 attn2 modules, 60 hooked, fp16, CFG batch 2,
+    tools/synthetic_unet.py) under ``daam_amd.trace`` -- incl. one compute_global_heat_map per generation -- minus its
+    step time with the stock fused-SDPA processor."""
+    import daam_amd
+    from tools.synthetic_unet import SyntheticPipeline
+    pipe = SyntheticPipeline('sdxl', 128, device=str(device))
+    prompt = 'a photo of a monkey riding a bicycle'
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def traced():
+        with daam_amd.trace(pipe) as tc:
+            pipe(prompt, num_inference_steps=steps)
+            return tc.compute_global_heat_map().heat_maps
+    t_plain = timed(lambda: pipe(prompt, num_inference_steps=steps))
+    t_trace = timed(traced)
+    t_plain2 = timed(lambda: pipe(prompt, num_inference_steps=steps))          # drift check: plain again after the traced runs
+    base = min(t_plain, t_plain2)
+    del pipe
+    torch.cuda.empty_cache()
+    return dict(harness='synthetic SDXL-1024 cross-attention stack, 70 attn2 (60 hooked), fp16, CFG 2, '
+                        f'{steps} steps + compute_global_heat_map per generation, {reps} generations',
+                plain_sdpa_ms_per_step=round(base / steps * 1e3, 3), traced_ms_per_step=round(t_trace / steps * 1e3, 3),
+                overhead_ms_per_step=round((t_trace - base) / steps * 1e3, 3))
+
+
+def _respawn_under_launcher(n):
+    """``python bench.py --gpus N`` (N > 1) without a launcher: run N ranks of this script under torch.distributed.run."""
+    import socket
+    import subprocess
+    if torch.cuda.device_count() < n:
+        raise SystemExit(f'--gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible: refusing to report another n_gpus')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def load_profile(name):
+    """A committed profiler summary (profiles/<name>) if it was measured on THIS build of the kernels, else None."""
+    from daam_amd.build import csrc_sha
+    path = os.path.join(ROOT, 'profiles', name)
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    if rec.get('csrc_sha') != csrc_sha():
+        return None, f'profiles/{name} was measured on kernel sources {rec.get("csrc_sha")}, this build is {csrc_sha()}'
+    return rec, f'profiles/{name} (rocprofv3 --pmc passes of this build, csrc {rec["csrc_sha"]}; not re-measured in this run)'
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -218,12 +355,15 @@ def main():
                     help='distinct synthetic Q/K step sets resident in HBM (0 = one per denoising step: no step of a '
                          'generation re-reads data an earlier one left in L2 / Infinity Cache)')
     ap.add_argument('--no-baselines', action='store_true', help='skip the CPU / eager-GPU reference timings')
+    ap.add_argument('--no-integrated', action='store_true', help='skip the integrated-overhead leg')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        _respawn_under_launcher(args.gpus)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
@@ -308,19 +448,36 @@ def main():
             launches_per_gen = args.denoise_steps * len(layers)
         achieved = bytes_launch / (tap_ms * 1e-3) / 1e9
         survey_bytes = spl * (qk_bytes + 2 * acc_total) if args.defer > 0 else bytes_launch   # RMW per step
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-        if os.path.exists(tpath):
-            try:
-                rec = json.load(open(tpath)).get(f'{args.workload}:defer{spl}:{args.accumulate}')
-                traffic = rec.get('tap_bytes_per_launch') if rec else None
-            except Exception:
-                traffic = None
-        roofline = dict(bound='hbm', kernel='tap_d64_kernel (16x16x32 MFMA tiles, head_dim 64)' if wl['kind'] == 'sdxl' else 'tap_mfma_kernel<KS=3|5|10>',
+        key = f'{args.workload}:defer{spl}:{args.accumulate}'
+        prof, prof_note = load_profile('r02_counters.json')
+        rec = (prof or {}).get('workloads', {}).get(key)
+        traffic = rec.get('tap_bytes_per_launch') if rec else None
+        tap_kernel = ('tap_d64_kernel (16x16x32 MFMA tiles, head_dim 64)' if wl['kind'] == 'sdxl'
+                      else 'tap_d64_kernel (head_dim 40) + tap_mfma_kernel<KS=5|10> (head_dim 80 / 160) side by side')
+        roofline = dict(bound='hbm', kernel=tap_kernel,
                         achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=traffic, bytes_per_launch=int(bytes_launch), ms_per_launch=round(tap_ms, 4),
+                        traffic=traffic, traffic_source=prof_note if rec else (prof_note or 'no PMC pass committed for this workload'),
+                        bytes_per_launch=int(bytes_launch), ms_per_launch=round(tap_ms, 4),
                         steps_per_launch=spl, launches_per_generation=launches_per_gen,
                         achieved_at_survey_8d_bytes=round(survey_bytes / (tap_ms * 1e-3) / 1e9, 1))
+        # ---- issue-rate roofline of the same launch: the deferred tap keeps the sums in registers, so its HBM work is the
+        # Q / K stream only and the kernel is bound by instruction issue (softmax VALU + MFMA).  Floor = (VALU busy cycles +
+        # MFMA instructions x the ~10 cycles each keeps the VALU port closed, tools/ubench_issue) per SIMD / shader clock.
+        roofline_issue = None
+        if args.defer > 0:
+            mon = ClockMonitor(eng, window_ms=40.0)
+            measure_tap_kernel(eng, calls, spl, reps=8, fresh=fresh)
+            clock = mon.read()
+            roofline_issue = dict(bound='issue', kernel=tap_kernel, clock=clock, ms_per_launch=round(tap_ms, 4))
+            if rec and clock and rec.get('tap_valu_busy_cycles_per_simd'):
+                cyc = rec['tap_valu_busy_cycles_per_simd'] + 10.0 * rec.get('tap_mfma_per_simd', 0)
+                floor_ms = cyc / (clock['mhz_median_under_load'] * 1e3)
+                roofline_issue.update(valu_busy_cycles_per_simd=rec['tap_valu_busy_cycles_per_simd'],
+                                      valu_insts_per_simd=rec.get('tap_valu_insts_per_simd'),
+                                      mfma_insts_per_simd=rec.get('tap_mfma_per_simd'), mfma_issue_block_cycles=10,
+                                      floor_ms=round(floor_ms, 4), frac=round(floor_ms / tap_ms, 4), source=prof_note)
+            else:
+                roofline_issue['note'] = prof_note or 'no PMC pass committed for this workload'
         # host cost of the per-layer call path for one generation (launches are asynchronous)
         torch.cuda.synchronize()
         th0 = time.perf_counter()
@@ -330,9 +487,22 @@ def main():
         eng.flush()
         host_ms = (time.perf_counter() - th0) * 1e3
         torch.cuda.synchronize()
-        fin_ms = measure_finalize(eng, reps=20)
+        mon = ClockMonitor(eng, window_ms=10.0, period_us=50)
+        fin_ms = measure_finalize(eng, reps=40)
+        fin_clock = mon.read()
         fin_bytes = acc_total + 77 * 64 * 64 * 4
         fin_gbs = fin_bytes / (fin_ms * 1e-3) / 1e9
+        fin_kernel = {'sdxl1024': 'table upload + zeroing, finalize_up32_same_kernel (x2 MFMA class and same-size class in one launch)',
+                      'sdxl2048': 'table upload + zeroing, finalize_down2 (128 -> 64) + finalize_same_kernel',
+                      'sd15': 'table upload + zeroing, finalize_same / finalize_up32_mfma / finalize_up_kernel<16>'}[args.workload]
+        fin_issue = dict(bound='issue', kernel=fin_kernel, clock=fin_clock, ms_per_launch=round(fin_ms, 4))
+        if rec and fin_clock and rec.get('finalize_valu_busy_cycles_per_simd'):
+            cyc = rec['finalize_valu_busy_cycles_per_simd'] + 32.0 * rec.get('finalize_mfma_per_simd', 0)
+            fl = cyc / (fin_clock['mhz_median_under_load'] * 1e3)
+            fin_issue.update(valu_busy_cycles_per_simd=rec['finalize_valu_busy_cycles_per_simd'],
+                             mfma_insts_per_simd=rec.get('finalize_mfma_per_simd'), mfma_cycles_each=32,
+                             model='VALU busy + matrix-pipe cycles (they add in this kernel: every VALU block consumes an MFMA result and feeds the next chain)',
+                             floor_ms=round(fl, 4), frac=round(fl / fin_ms, 4), source=prof_note)
         gpu_ms_per_gen = launches_per_gen * tap_ms + fin_ms
         extra = dict(
             extraction_overhead_ms_per_denoise_step=round((elapsed / args.steps * 1e3) / args.denoise_steps, 4),
@@ -340,13 +510,16 @@ def main():
             gpu_bound_maps_per_s=round(1e3 / gpu_ms_per_gen, 1),
             host_enqueue_ms_per_generation=round(host_ms, 3),
             raw_maps_per_s=round(world * args.steps * args.denoise_steps * sum(h for _, h, _, _ in layers) / elapsed, 1),
-            roofline_finalize=dict(bound='hbm', kernel='table upload + zeroing, finalize_up32_same_kernel (x2 MFMA class and same-size class in one launch)', achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
+            roofline_finalize=dict(bound='hbm', kernel=fin_kernel, achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
                                    unit='GB/s', frac=round(fin_gbs / HBM_PEAK_GBS, 4), bytes_per_launch=int(fin_bytes),
-                                   ms_per_launch=round(fin_ms, 4)),
+                                   ms_per_launch=round(fin_ms, 4), traffic=rec.get('finalize_bytes_per_launch') if rec else None),
+            roofline_issue=roofline_issue, roofline_finalize_issue=fin_issue,
         )
         eng.close()
         del sets
         torch.cuda.empty_cache()
+        if not args.no_integrated and world == 1 and args.workload == 'sdxl1024':
+            extra['integrated'] = integrated_overhead(device)
         cpu = None
         if not args.no_baselines and world == 1:
             cpu = cpu_baseline(wl['kind'], wl['latent'], args.denoise_steps, eager_device=device)

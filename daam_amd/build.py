@@ -12,6 +12,17 @@ HEADERS = ['daam_types.h', 'daam_tap_common.h', os.path.join('..', '..', 'includ
 OUT = os.path.join(HERE, 'libdaam_hip.so')
 
 
+def csrc_sha() -> str:
+    """Fingerprint of the kernel sources (csrc/*.hip, *.h and the C header): ties committed profiler summaries
+    (profiles/*.json) to the build they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(HERE, 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def hipcc() -> str:
     exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(exe):
@@ -48,6 +59,17 @@ def build_fastpath(force: bool = False, verbose: bool = True) -> str:
            '-I' + sysconfig.get_paths()['include'], *['-I' + p for p in ext.include_paths()],
            src, '-o', out, *['-L' + p for p in lib_dirs], *['-Wl,-rpath,' + p for p in lib_dirs],
            '-ltorch_python', '-ltorch', '-ltorch_cpu', '-lc10']
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return out
+
+
+def build_variant(out: str, flags, verbose: bool = True) -> str:
+    """A/B builds for kernel experiments (tools/): the same sources with extra ``-D`` flags into another file; load it with
+    ``DAAM_HIP_LIB=<out>``."""
+    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fvisibility=hidden', *flags,
+           *[os.path.join(HERE, 'csrc', f) for f in SOURCES], '-o', out]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)

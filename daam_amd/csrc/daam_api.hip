@@ -34,6 +34,8 @@ hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
 hipError_t launch_finalize_up(const FinLaunch&, int side, int, int mfma_ok, hipStream_t, int*);
 bool finalize_up_supported(int side, int out_side);
 hipError_t launch_normalize(float*, int, int, hipStream_t);
+hipError_t launch_clock_monitor(unsigned long long* samples, int n_samples, int period_us, hipStream_t);
+constexpr int kClockMaxSamples = 4096;
 hipError_t launch_word(const float*, int, const int32_t*, int, float*, float*, int, int, int, float, float*,
                        hipStream_t);
 }  // namespace daam
@@ -185,6 +187,12 @@ struct DaamCtx {
     int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
     int profile = 0;
     hipEvent_t prof_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    // shader-clock monitor (daam_clock_monitor_*): one wave on its own stream samples the shader-cycle counter and the
+    // 100 MHz reference counter into pinned memory while the kernels under test run
+    unsigned long long* clk_host = nullptr;
+    unsigned long long* clk_dev = nullptr;
+    int clk_samples = 0;
+    hipStream_t clk_stream = nullptr;
     static constexpr int kAux = 3;     // side streams of multi-kind tap flushes (see daam_tap_flush)
     hipStream_t aux_stream[kAux] = {nullptr, nullptr, nullptr};
     hipEvent_t aux_fork = nullptr, aux_join[kAux] = {nullptr, nullptr, nullptr};
@@ -342,6 +350,8 @@ int daam_ctx_destroy(DaamCtx* c)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& st : c->aux_stream)
         if (st) (void)hipStreamDestroy(st);
+    if (c->clk_stream) (void)hipStreamDestroy(c->clk_stream);
+    if (c->clk_host) (void)hipHostFree(c->clk_host);
     if (c->d_up32_ops) (void)hipFree(c->d_up32_ops);
     if (c->d_tab_idx) (void)hipFree(c->d_tab_idx);
     if (c->d_tab_w) (void)hipFree(c->d_tab_w);
@@ -947,6 +957,7 @@ int daam_profile_enable(DaamCtx* c, int on)
     if (on && !c->prof_ev[0][0])
         for (auto& pair : c->prof_ev)
             for (auto& ev : pair) HIP_TRY(hipEventCreate(&ev));
+
     c->profile = on ? 1 : 0;
     return 0;
 }
@@ -957,6 +968,38 @@ int daam_profile_last_ms(DaamCtx* c, int which, float* ms)
     if (!c->prof_ev[which][0]) return fail(DAAM_E_STATE, "profiling was never enabled");
     HIP_TRY(hipEventSynchronize(c->prof_ev[which][1]));
     HIP_TRY(hipEventElapsedTime(ms, c->prof_ev[which][0], c->prof_ev[which][1]));
+    return 0;
+}
+
+int daam_clock_monitor_start(DaamCtx* c, int n_samples, int period_us)
+{
+    if (!c || n_samples < 2 || n_samples > kClockMaxSamples || period_us < 1) return fail(DAAM_E_INVALID, "bad argument");
+    DeviceGuard on_device(c);
+    if (!c->clk_host) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->clk_host), 2 * kClockMaxSamples * sizeof(unsigned long long), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->clk_dev), c->clk_host, 0));
+        HIP_TRY(hipStreamCreateWithFlags(&c->clk_stream, hipStreamNonBlocking));
+    }
+    HIP_TRY(hipStreamSynchronize(c->clk_stream));
+    memset(c->clk_host, 0, 2 * kClockMaxSamples * sizeof(unsigned long long));
+    c->clk_samples = n_samples;
+    hipError_t e = launch_clock_monitor(c->clk_dev, n_samples, period_us, c->clk_stream);
+    if (e != hipSuccess) return fail((int)e, "clock monitor launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int daam_clock_monitor_read(DaamCtx* c, float* mhz, int capacity, int* n_intervals)
+{
+    if (!c || !mhz || !n_intervals) return fail(DAAM_E_INVALID, "NULL argument");
+    if (!c->clk_host || c->clk_samples < 2) return fail(DAAM_E_STATE, "the clock monitor was never started");
+    DeviceGuard on_device(c);
+    HIP_TRY(hipStreamSynchronize(c->clk_stream));
+    int n = 0;
+    for (int i = 1; i < c->clk_samples && n < capacity; ++i) {
+        const unsigned long long* a = c->clk_host + 2 * (i - 1), *b = c->clk_host + 2 * i;
+        if (b[1] > a[1] && b[0] > a[0]) mhz[n++] = (float)((double)(b[0] - a[0]) / (double)(b[1] - a[1]) * 100.0);   // reference: 100 MHz
+    }
+    *n_intervals = n;
     return 0;
 }
 

@@ -29,6 +29,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 template <typename T> struct Plane;
 template <> struct Plane<_Float16> {
@@ -259,8 +260,6 @@ __global__ __launch_bounds__(256) void finalize_up_kernel(const FinLaunch L)
                     [&](int i) { return i * O + lane; }, L.out + (size_t)tok * O * O, L.inv_n);
 }
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
 // ---------------------------------------------------------------------------------------
 // x2 (32 -> 64) for fp16 planes with BOTH bicubic passes on the matrix cores.
 //   pass 1 (x):  T = P Wx^T on v_mfma_f32_32x32x16_f16.  The A operand is the plane itself, 16 bytes per
@@ -287,6 +286,41 @@ __device__ __forceinline__ half2v fin_cvt_pk(float a, float b) {
     half2v r;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+}
+
+// t - f32(h.lo) / t - f32(h.hi): one mixed-precision FMA straight from the packed fp16 pair
+__device__ __forceinline__ float fin_sub_lo(float t, half2v h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(t));
+    return r;
+}
+__device__ __forceinline__ float fin_sub_hi(float t, half2v h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(t));
+    return r;
+}
+// max(a, b) for b >= 0 through the integer order of the bit patterns: one v_max_i32, no NaN canonicalisation in front
+// (fmaxf() costs a second v_max_f32), and -- unlike an inline-asm v_max_f32 -- visible to the compiler's hazard
+// recognizer, which pads the MFMA-result -> VALU-read wait states.  b >= 0: a negative a has its sign bit set and loses
+// as an integer, two non-negative floats order like their bit patterns.
+__device__ __forceinline__ float fin_max_nonneg(float a, float b) {
+    const int x = __float_as_int(a), y = __float_as_int(b);
+    return __int_as_float(x > y ? x : y);
+}
+// D = A B + C into NEW registers (C stays intact).  The builtin always comes out in the tied form (vdst = srcC) here, which
+// costs a 16-register copy of the running sums in front of every chain; the three-address form does the "copy" in the
+// matrix pipe.  Hazards of an MFMA hidden in an asm statement (cdna_hip_programming.md section 5.7): its A / B / C operands
+// may have been written by the VALU instruction right before it (v_cvt_pk / v_max) -> s_nop 1 in front; its result is
+// consumed only by the next MFMA of the chain, which takes it whole as C (no wait states needed); everything that READS
+// an MFMA result with the VALU is compiler-generated code (no inline asm), so those wait states are padded for us.
+__device__ __forceinline__ floatx16 fin_mfma_from(const half8& a, const half8& b, const floatx16& c) {
+#ifdef DAAM_FIN_TIED_MFMA
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+    floatx16 d;
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#endif
 }
 
 // body: workgroup (tok, chunk) of n_chunks key chunks
@@ -332,6 +366,15 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
     for (int d = 0; d < kDepth; ++d)
         if (d < nk) fetch(d, pre[d]);
 
+    // Issue budget per half plane (tools/ubench_issue.hip, gfx950): an MFMA 32x32x16 holds the matrix pipe for 32 cycles and
+    // blocks VALU issue for ~10 of them; VALU of this and of the SIMD's other waves runs under the rest.  10 MFMAs =
+    // 326 cycles of matrix pipe; the VALU side is 8 + 8 v_cvt_pk_f16_f32 and 16 v_fma_mix_f32 (5 cycles each) for the
+    // hi / lo split and 32 v_max_f32 (4 cycles) = 288 cycles + 100 blocked: the two pipes are about balanced.
+    //   * clamp + accumulate costs ONE v_max per output: pass 2 starts from the running sums (C = acc), so its result is
+    //     D = acc + o and  acc + max(o, 0) == max(D, acc)  (fl(acc + o) >= acc exactly when o >= 0);
+    //   * lo = T - hi is one mixed-precision FMA straight from the packed fp16 hi (written as T - (float)hi it becomes
+    //     v_cvt_f32_f16 + v_sub_f32);
+    //   * the max is v_max_i32 on the bit patterns (the sums are never negative): fmaxf() would add a canonicalising v_max.
     for (int i0 = 0; i0 < nk; i0 += kDepth) {
 #pragma unroll
       for (int d = 0; d < kDepth; ++d) {
@@ -339,20 +382,26 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
         if (ki >= nk) break;
         floatx16 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][0], wx[0], floatx16{0}, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][1], wx[1], c, 0, 0, 0);
+#if !defined(DAAM_FIN_ABLATE) || DAAM_FIN_ABLATE != 1       // experiment 1: no plane fetches after the first kDepth
         if (ki + kDepth < nk) fetch(ki + kDepth, pre[d]);
+#endif
         half8 bhi[2], blo[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 8; i += 2) {
                 const float t0 = c[8 * ks + i], t1 = c[8 * ks + i + 1];
-                const half2v hi = fin_cvt_pk(t0, t1);
-                const half2v lo = fin_cvt_pk(t0 - (float)hi[0], t1 - (float)hi[1]);
+                // hi: compiler-generated v_cvt_pk_f16_f32 (RNE) -- the first VALU read of the MFMA result, padded by the
+                // hazard recognizer; lo = T - hi: v_fma_mix_f32 through asm (left to itself the compiler vectorises the
+                // pair into v_cvt_f32_f16 x2 + v_pk_fma_f32, which cannot run beside the matrix pipe); it depends on hi,
+                // so it issues after that padded read
+                const half2v hi = __builtin_convertvector(float2v{t0, t1}, half2v);
+                const half2v lo = __builtin_convertvector(float2v{fin_sub_lo(t0, hi), fin_sub_hi(t1, hi)}, half2v);
                 bhi[ks][i] = hi[0]; bhi[ks][i + 1] = hi[1];
                 blo[ks][i] = lo[0]; blo[ks][i + 1] = lo[1];
             }
-        floatx16 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[0][0], bhi[0], floatx16{0}, 0, 0, 0);
-        floatx16 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[1][0], bhi[0], floatx16{0}, 0, 0, 0);
+        floatx16 o0 = fin_mfma_from(wy[0][0], bhi[0], acc[0]);
+        floatx16 o1 = fin_mfma_from(wy[1][0], bhi[0], acc[1]);
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[0][1], bhi[1], o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[1][1], bhi[1], o1, 0, 0, 0);
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[0][0], blo[0], o0, 0, 0, 0);
@@ -361,8 +410,8 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wy[1][1], blo[1], o1, 0, 0, 0);
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            acc[0][v] += fmaxf(o0[v], 0.f);
-            acc[1][v] += fmaxf(o1[v], 0.f);
+            acc[0][v] = fin_max_nonneg(o0[v], acc[0][v]);
+            acc[1][v] = fin_max_nonneg(o1[v], acc[1][v]);
         }
       }
     }
@@ -391,7 +440,7 @@ __global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLau
 
 #ifdef DAAM_FIN_TIMING
 }  // namespace daam
-extern "C" int daam_debug_dump_fin(unsigned long long* dst) {
+extern "C" __attribute__((visibility("default"))) int daam_debug_dump_fin(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(daam::daam_fin_dbg), sizeof(daam::daam_fin_dbg));
 }
 namespace daam {

@@ -454,6 +454,29 @@ hipError_t launch_finalize(const FinLaunch& L, int acc_dtype, hipStream_t stream
     return hipGetLastError();
 }
 
+// Shader-clock monitor (daam_clock_monitor_start): ONE wave; lane 0 stores (shader cycles, 100 MHz reference ticks) every
+// `period_us`, sleeping in between (s_sleep keeps it off the issue ports of the kernels under test).
+__global__ __launch_bounds__(64) void clock_monitor_kernel(unsigned long long* samples, int n_samples, int period_us)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long period = (unsigned long long)period_us * 100ull;       // reference ticks
+    unsigned long long next = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < n_samples; ++i) {
+        while (__builtin_amdgcn_s_memrealtime() < next) __builtin_amdgcn_s_sleep(32);
+        const unsigned long long cyc = __builtin_amdgcn_s_memtime();
+        const unsigned long long ref = __builtin_amdgcn_s_memrealtime();
+        __hip_atomic_store(samples + 2 * i, cyc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(samples + 2 * i + 1, ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        next = ref + period;
+    }
+}
+
+hipError_t launch_clock_monitor(unsigned long long* samples, int n_samples, int period_us, hipStream_t stream)
+{
+    hipLaunchKernelGGL(clock_monitor_kernel, dim3(1), dim3(64), 0, stream, samples, n_samples, period_us);
+    return hipGetLastError();
+}
+
 hipError_t launch_normalize(float* maps, int n_rows, int plane, hipStream_t stream)
 {
     hipLaunchKernelGGL(normalize_kernel, dim3((plane + 255) / 256), dim3(256), 0, stream, maps, n_rows, plane);

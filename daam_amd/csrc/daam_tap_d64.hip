@@ -163,10 +163,12 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
         const bool pow2 = (__float_as_uint(lay.scale) & 0x007fffffu) == 0;      // wave-uniform
         half2v xh[kSlots16 / 2];
         if (pow2) {
+            // compiler-generated v_cvt_pk_f16_f32 (not the asm helper): this is the first VALU read of the MFMA results,
+            // and only instructions the compiler can see get their MFMA -> VALU wait states padded
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
-                xh[2 * mt] = cvt_pk_rne(float2v{c[mt][0], c[mt][1]});
-                xh[2 * mt + 1] = cvt_pk_rne(float2v{c[mt][2], c[mt][3]});
+                xh[2 * mt] = __builtin_convertvector(float2v{c[mt][0], c[mt][1]}, half2v);
+                xh[2 * mt + 1] = __builtin_convertvector(float2v{c[mt][2], c[mt][3]}, half2v);
             }
         } else {
 #pragma unroll

@@ -229,7 +229,7 @@ bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t 
 }
 
 #if defined(DAAM_ABLATE) && DAAM_ABLATE == 9
-extern "C" int daam_debug_dump(unsigned long long* dst) {
+extern "C" __attribute__((visibility("default"))) int daam_debug_dump(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(daam_dbg), sizeof(unsigned long long) * 1024 * 8);
 }
 #endif

@@ -39,7 +39,14 @@ def gather_heat_maps(local_maps: torch.Tensor, n_items: int, group=None) -> torc
     if pad:
         local_maps = torch.cat([local_maps, local_maps.new_zeros((pad,) + tuple(local_maps.shape[1:]))])
     out = local_maps.new_empty((world * per,) + tuple(local_maps.shape[1:]))
-    dist.all_gather_into_tensor(out, local_maps.contiguous(), group=group)
+    if local_maps.device.type == 'cuda' and dist.get_backend(group) == 'gloo':
+        # gloo moves device tensors through the host anyway; do it explicitly (functional tests with several ranks on
+        # one device -- the production backend is nccl = RCCL over xGMI)
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local_maps.contiguous().cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, local_maps.contiguous(), group=group)
     # out[r * per + j] is item r + j * world
     out = out.view((world, per) + tuple(local_maps.shape[1:])).transpose(0, 1).reshape((world * per,) + tuple(local_maps.shape[1:]))
     return out[:n_items]

@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import sys
 import weakref
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
@@ -164,8 +165,7 @@ class HeatMapEngine:
         self._drop_recorded()
 
     def __del__(self):
-        import sys
-        if sys.is_finalizing():          # no HIP calls while the interpreter (and the HIP runtime) shut down
+        if sys is None or sys.is_finalizing():          # no HIP calls while the interpreter (and the HIP runtime) shut down
             return
         try:
             self.close()

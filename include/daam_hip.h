@@ -158,6 +158,13 @@ DAAM_API int daam_last_launch(DaamCtx* ctx, int which /*0 tap,1 finalize*/, int*
  * last pair and returns the elapsed milliseconds (the only other call that synchronises the host). */
 DAAM_API int daam_profile_enable(DaamCtx* ctx, int on);
 DAAM_API int daam_profile_last_ms(DaamCtx* ctx, int which /*0 tap,1 finalize*/, float* ms);
+/* Shader-clock monitor for issue-rate rooflines: one wave on an internal stream takes `n_samples` (<= 4096) samples, `period_us`
+ * apart, of the shader-cycle counter (s_memtime) and the constant 100 MHz reference counter (s_memrealtime) while the caller
+ * runs the kernels under test on its own stream; _read waits for the monitor and returns the clock of every sampling
+ * interval in MHz (delta cycles / delta reference x 100) -- the sustained clock under THAT load, which no host-side
+ * sampler resolves for a 2 ms kernel.  The kernels under test are not instrumented. */
+DAAM_API int daam_clock_monitor_start(DaamCtx* ctx, int n_samples, int period_us);
+DAAM_API int daam_clock_monitor_read(DaamCtx* ctx, float* mhz, int capacity, int* n_intervals);
 
 #ifdef __cplusplus
 }

@@ -126,10 +126,15 @@ class FakeAttention(nn.Module):
 
 
 class DefaultProcessor:
-    """What a stock pipeline would run when DAAM is not hooked (materialised attention)."""
+    """What a stock pipeline would run when DAAM is not hooked (diffusers 0.21.2 ``AttnProcessor``: materialised
+    attention; the mask is prepared for the KEY length, ``norm_cross`` is applied to the encoder states)."""
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
         ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        batch, key_length, _ = ctx.shape
+        attention_mask = attn.prepare_attention_mask(attention_mask, key_length, batch)
+        if encoder_hidden_states is not None and attn.norm_cross is not None:
+            ctx = attn.norm_cross(ctx)
         q = attn.head_to_batch_dim(attn.to_q(hidden_states))
         k = attn.head_to_batch_dim(attn.to_k(ctx))
         v = attn.head_to_batch_dim(attn.to_v(ctx))

@@ -138,12 +138,14 @@ def test_full_size_parity_with_reference_processor(sdxl_stack):
         g = got_raw[key].float().cpu().numpy().astype(np.float64)
         w = want.float().cpu().numpy().astype(np.float64)
         d = np.abs(g - w)
-        ulps = d / _ulp16(np.maximum(np.abs(g), np.abs(w)))
-        worst_ulps = max(worst_ulps, float(ulps.max()))
+        # a logit that lands on the other side of an fp16 rounding boundary (GEMM summation order) moves that step's
+        # probabilities by up to e^(2^-6) - 1 = 1.6 % (tests/test_gpu_fullsize.py): relative + 2 ulp per element
+        excess = d - (2.0 ** -6 * np.abs(w) + 2 * _ulp16(np.maximum(np.abs(g), np.abs(w))))
+        worst_ulps = max(worst_ulps, float((d / _ulp16(np.maximum(np.abs(g), np.abs(w)))).max()))
         frac_diff = max(frac_diff, float((d > 0).mean()))
+        assert excess.max() <= 0, f'key {key}: off by {d.flat[np.argmax(excess)]} at value {w.flat[np.argmax(excess)]}'
         assert d.max() <= _ulp16(np.asarray(w.max())) + 1e-12, f'key {key}: {d.max()} > 1 ulp of the largest sum {w.max()}'
-    assert worst_ulps <= 2.0, f'running sums differ by {worst_ulps} ulp'
-    assert frac_diff <= 0.05, f'{frac_diff:.3%} of a key differ'
+    assert frac_diff <= 0.02, f'{frac_diff:.3%} of a key differ'
 
     # (3) what the processors returned (last step, every attn2 incl. the un-hooked mid block)
     worst_out = 0.0

@@ -457,6 +457,34 @@ def test_torch_port_matches_reference_golden(name):
     assert len(th.topology('sd15')) == 15 and sum(h for _, h, _, _ in th.topology('sd15')) == 120
 
 
+@pytest.mark.parametrize('name', ['sd15_f32', 'sdxl_heads_f32', 'sd15_upcast_attn_f16'])
+def test_torch_port_processor_matches_reference_golden(name):
+    """``oracle.torch_hooks.ReferenceProcessor`` (the reference's processor restated, used as the yardstick of the
+    full-size GPU parity tests) returns what the REFERENCE's processor returned and taps the same maps."""
+    from oracle import torch_hooks as th
+    from oracle.make_golden import OUT_SAMPLE_ROWS
+    z, meta = load_golden(name)
+    pipe = golden_pipe(meta)
+    pipe.keep_outputs = True
+    modules, _ = ho.locate(pipe.unet, locate_middle_block=bool(meta.get('heads')))
+    raw = th.RawMaps()
+    lat = ho.latent_hw_for(pipe.unet.config.sample_size, pipe.vae_scale_factor)
+    for idx, m in enumerate(modules):
+        m.set_processor(th.ReferenceProcessor(raw, idx, lat))
+    pipe(meta['prompt'], num_inference_steps=meta['steps'])
+    assert np.array_equal(np.asarray([k for k, _ in raw], dtype=np.int32), z['keys'])
+    rel = 1e-6 if meta['dtype'] == 'float32' else 1e-3
+    for i, o in enumerate(pipe.last_outputs):
+        want = z[f'out_rows_{i}']
+        got = o[-1, :OUT_SAMPLE_ROWS].float().numpy()
+        assert np.abs(got - want).max() <= rel * max(float(np.abs(want).max()), 1e-6)
+        assert abs(float((o.double() ** 2).sum()) - z['out_sums'][i, 1]) <= 4 * rel * z['out_sums'][i, 1]
+    n_rows = len(pipe.tokenizer.tokenize(meta['prompt'])) + 2
+    got = th.global_heat_map(raw, lat, n_rows=n_rows).numpy()
+    np.testing.assert_allclose(got, z['global_default'], rtol=0, atol=(2e-6 if meta['dtype'] == 'float32' else 2e-4) *
+                               max(1.0, float(np.abs(z['global_default']).max())))
+
+
 # ------------------------------------------------------------------------------------------------
 # GenerationExperiment: the reference's on-disk layout (experiment.py:140-167, 303-344)
 # ------------------------------------------------------------------------------------------------
