@@ -278,7 +278,7 @@ def _port_eager_on_device(th, kind, latent, denoise_steps, device, sample_steps=
                 maps_per_s=1.0 / (per_step * denoise_steps + t_fin))
 
 
-def integrated_overhead(device, steps=20, reps=3):
+def integrated_overhead(device, steps=20, reps=7):
     """Extraction overhead per denoising step INSIDE a model-shaped stack (metric (i), integrated harness):
     step time of a full-size synthetic SDXL-1024 cross-attention stack (70 attn2 modules, 60 hooked, fp16, CFG batch 2,
     tools/synthetic_unet.py) under ``daam_amd.trace`` -- incl. one compute_global_heat_map per generation -- minus its
@@ -288,29 +288,39 @@ def integrated_overhead(device, steps=20, reps=3):
     pipe = SyntheticPipeline('sdxl', 128, device=str(device))
     prompt = 'a photo of a monkey riding a bicycle'
 
-    def timed(fn):
-        fn()
+    def once(fn):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
+        fn()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
+        return time.perf_counter() - t0
 
     def traced():
         with daam_amd.trace(pipe) as tc:
             pipe(prompt, num_inference_steps=steps)
             return tc.compute_global_heat_map().heat_maps
-    t_plain = timed(lambda: pipe(prompt, num_inference_steps=steps))
-    t_trace = timed(traced)
-    t_plain2 = timed(lambda: pipe(prompt, num_inference_steps=steps))          # drift check: plain again after the traced runs
-    base = min(t_plain, t_plain2)
+
+    def plain():
+        pipe(prompt, num_inference_steps=steps)
+    for _ in range(2):                                   # warm-up: code objects, allocator pools, parked trace context, clocks
+        plain()
+        traced()
+    # interleaved A / B generations and medians: the difference of two ~9 ms step times is what is measured, so clock
+    # ramps and allocator drift must hit both arms alike
+    tp, tt = [], []
+    for _ in range(reps):
+        tp.append(once(plain))
+        tt.append(once(traced))
+    tp.sort()
+    tt.sort()
+    t_plain, t_trace = tp[len(tp) // 2], tt[len(tt) // 2]
     del pipe
     torch.cuda.empty_cache()
     return dict(harness='synthetic SDXL-1024 cross-attention stack, 70 attn2 (60 hooked), fp16, CFG 2, '
-                        f'{steps} steps + compute_global_heat_map per generation, {reps} generations',
-                plain_sdpa_ms_per_step=round(base / steps * 1e3, 3), traced_ms_per_step=round(t_trace / steps * 1e3, 3),
-                overhead_ms_per_step=round((t_trace - base) / steps * 1e3, 3))
+                        f'{steps} steps + compute_global_heat_map per generation; medians of {reps} interleaved plain / traced generations',
+                plain_sdpa_ms_per_step=round(t_plain / steps * 1e3, 3), traced_ms_per_step=round(t_trace / steps * 1e3, 3),
+                overhead_ms_per_step=round((t_trace - t_plain) / steps * 1e3, 3),
+                spread_ms_per_step=round(max(tp[-1] - tp[0], tt[-1] - tt[0]) / steps * 1e3, 3))
 
 
 def _respawn_under_launcher(n):
@@ -465,7 +475,7 @@ def main():
         # MFMA instructions x the ~10 cycles each keeps the VALU port closed, tools/ubench_issue) per SIMD / shader clock.
         roofline_issue = None
         if args.defer > 0:
-            mon = ClockMonitor(eng, window_ms=40.0)
+            mon = ClockMonitor(eng, window_ms=40.0)                  # second pass with the monitor wave running beside the kernel
             measure_tap_kernel(eng, calls, spl, reps=8, fresh=fresh)
             clock = mon.read()
             roofline_issue = dict(bound='issue', kernel=tap_kernel, clock=clock, ms_per_launch=round(tap_ms, 4))
@@ -487,8 +497,9 @@ def main():
         eng.flush()
         host_ms = (time.perf_counter() - th0) * 1e3
         torch.cuda.synchronize()
-        mon = ClockMonitor(eng, window_ms=10.0, period_us=50)
         fin_ms = measure_finalize(eng, reps=40)
+        mon = ClockMonitor(eng, window_ms=10.0, period_us=50)       # the clock in a second pass: the monitor wave is kept out of the timing
+        measure_finalize(eng, reps=60)
         fin_clock = mon.read()
         fin_bytes = acc_total + 77 * 64 * 64 * 4
         fin_gbs = fin_bytes / (fin_ms * 1e-3) / 1e9

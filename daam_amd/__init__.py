@@ -6,5 +6,6 @@ from .utils import *         # noqa: F401,F403
 from .heatmap import *       # noqa: F401,F403
 from .trace import *         # noqa: F401,F403
 from .experiment import GenerationExperiment  # noqa: F401
+from .evaluate import compute_iou, compute_ioa  # noqa: F401
 
 __version__ = '0.1.0'

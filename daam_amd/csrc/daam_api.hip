@@ -34,6 +34,7 @@ hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
 hipError_t launch_finalize_up(const FinLaunch&, int side, int, int mfma_ok, hipStream_t, int*);
 bool finalize_up_supported(int side, int out_side);
 hipError_t launch_normalize(float*, int, int, hipStream_t);
+hipError_t launch_mask_overlap(const float*, int, int, const float*, int, int, int, float*, hipStream_t);
 hipError_t launch_clock_monitor(unsigned long long* samples, int n_samples, int period_us, hipStream_t);
 constexpr int kClockMaxSamples = 4096;
 hipError_t launch_word(const float*, int, const int32_t*, int, float*, float*, int, int, int, float, float*,
@@ -281,6 +282,18 @@ static std::vector<_Float16> build_up32_ops(const int16_t* idx, const float* w)
                         dst[(2 + 2 * t + ks) * 8 + i] = W(32 * t + n, 16 * ks + 8 * (i >> 2) + 4 * g + (i & 3));
         }
     return ops;
+}
+
+// Key ranges of the chunks of the x2 MFMA finalize: equal shares (even boundaries; the two key lanes of a workgroup take the
+// keys of its range alternately).  Shares shrinking with the dispatch round of a chunk's workgroups (the SIMD arbitrates by
+// age: the first 256 workgroups finish their loop in 23 us, the last 256 in 40 us) were tried and changed nothing -- the kernel
+// is throughput-bound from its first to its last microsecond, the age order only decides who waits.
+static void finalize_chunk_ranges(int n_keys, int n_chunks, FinLaunch* L)
+{
+    const int pairs = (n_keys + 1) / 2;
+    for (int c = 0; c <= n_chunks; ++c)
+        L->chunk_begin[c] = (int16_t)std::min(n_keys, 2 * (int)(((int64_t)pairs * c + n_chunks - 1) / n_chunks));
+    L->chunk_begin[n_chunks] = (int16_t)n_keys;
 }
 
 extern "C" {
@@ -852,22 +865,12 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     hipStream_t s = (hipStream_t)stream;
     const size_t plane = (size_t)c->out_side * c->out_side;
     const size_t out_bytes = sizeof(float) * c->tokens * plane;
-    const bool zero_in_upload = out_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    if (!zero_in_upload) HIP_TRY(hipMemsetAsync(out, 0, out_bytes, s));
     size_t off = 0;
     const size_t bytes = (size_t)total * sizeof(FinKey);
     HIP_TRY(c->ring.alloc(bytes, &off));
     {
         FinKey* dst = reinterpret_cast<FinKey*>(c->ring.host + off);
         for (auto& v : keys) { memcpy(dst, v.data(), v.size() * sizeof(FinKey)); dst += v.size(); }
-    }
-    if (c->profile) (void)hipEventRecord(c->prof_ev[1][0], s);    // timed: table upload + zeroing + the class kernels
-    {
-        hipError_t ce = c->ring.commit(off, bytes, s, zero_in_upload ? out : nullptr, zero_in_upload ? out_bytes : 0);
-        if (ce != hipSuccess) {
-            (void)c->ring.release(s);
-            return fail((int)ce, "table upload: %s", hipGetErrorString(ce));
-        }
     }
     const FinKey* dev = reinterpret_cast<const FinKey*>(c->ring.dev + off);
     c->last_block[1] = 256;
@@ -902,13 +905,31 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             // more pays the per-workgroup reduction + atomics too often.
             const int want = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
             L.n_chunks = std::max(std::max(1, std::min((n + 3) / 4, want)), (n + 127) / 128);   // <= 64 keys per wave (2 or 4 key lanes per workgroup)
+            L.n_chunks = std::min(L.n_chunks, kFinMaxChunks);
         }
+        memset(L.chunk_begin, 0, sizeof L.chunk_begin);
+        if (cls == 1) finalize_chunk_ranges(n, L.n_chunks, &L);
         have[cls] = true;
     }
     const bool mfma_up = have[1] && c->acc_dtype == DAAM_F16 && launches[1].mfma_ops &&
-                         c->tab_fp16_exact[keys[1][0].tab] && !c->no_mfma_finalize;
+                         c->tab_fp16_exact[keys[1][0].tab] && !c->no_mfma_finalize &&
+                         (int)keys[1].size() <= kFinMaxChunks * 128;          // chunk table of the MFMA kernel: 31 chunks x 2 x 64 keys
     // SDXL-1024 in fp16: the same-size and the x2 class side by side in ONE launch
     const bool paired = mfma_up && have[0] && !c->no_paired_finalize;
+    // the output is accumulated with atomics: zero it in the table-upload launch
+    const bool zero_in_upload = out_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    if (!zero_in_upload) {
+        hipError_t ze = hipMemsetAsync(out, 0, out_bytes, s);
+        if (ze != hipSuccess) { (void)c->ring.release(s); return fail((int)ze, "output memset: %s", hipGetErrorString(ze)); }
+    }
+    if (c->profile) (void)hipEventRecord(c->prof_ev[1][0], s);    // timed: table upload + zeroing + the class kernels
+    {
+        hipError_t ce = c->ring.commit(off, bytes, s, zero_in_upload ? out : nullptr, zero_in_upload ? out_bytes : 0);
+        if (ce != hipSuccess) {
+            (void)c->ring.release(s);
+            return fail((int)ce, "table upload: %s", hipGetErrorString(ce));
+        }
+    }
     for (int cls = 0; cls < 4; ++cls) {
         if (!have[cls] || (paired && cls == 0)) continue;
         const FinLaunch& L = launches[cls];
@@ -947,6 +968,18 @@ int daam_word_heat_map(const float* maps, int side, const int32_t* idx, int n_id
     hipError_t e = launch_word(maps, side, idx, n_idx, word_map, out, out_h, out_w, absolute, threshold, workspace,
                                (hipStream_t)stream);
     if (e != hipSuccess) return fail((int)e, "word map launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int daam_mask_overlap(const float* a, int a_h, int a_w, const float* b, int b_h, int b_w, int n_pairs, float* sums, void* stream)
+{
+    if (!a || !b || !sums) return fail(DAAM_E_INVALID, "NULL argument");
+    if (n_pairs <= 0 || n_pairs > 65535 || a_h <= 0 || a_w <= 0 || b_h <= 0 || b_w <= 0 || (long long)b_h * b_w > (1ll << 30))
+        return fail(DAAM_E_INVALID, "bad shape: %d pairs, a %dx%d, b %dx%d", n_pairs, a_h, a_w, b_h, b_w);
+    if (a_h == b_h && a_w != b_w)
+        return fail(DAAM_E_INVALID, "same heights but widths %d / %d differ (the reference's a * b would not broadcast)", a_w, b_w);
+    hipError_t e = launch_mask_overlap(a, a_h, a_w, b, b_h, b_w, n_pairs, sums, (hipStream_t)stream);
+    if (e != hipSuccess) return fail((int)e, "mask overlap launch: %s", hipGetErrorString(e));
     return 0;
 }
 

@@ -323,6 +323,15 @@ __device__ __forceinline__ floatx16 fin_mfma_from(const half8& a, const half8& b
 #endif
 }
 
+// tunables of the x2 MFMA kernel (overridable for A/B builds): planes prefetched ahead per wave, waves per SIMD the register
+// allocator must leave room for
+#ifndef DAAM_FIN_KDEPTH
+#define DAAM_FIN_KDEPTH 2
+#endif
+#ifndef DAAM_FIN_WAVES
+#define DAAM_FIN_WAVES 4
+#endif
+
 // body: workgroup (tok, chunk) of n_chunks key chunks
 __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, const int tok, const int chunk, const int n_chunks)
 {
@@ -330,11 +339,12 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
     // output per wave keeps the kernel under 128 VGPRs (4 waves per SIMD: the MFMA chain of one wave
     // runs under the VALU work of the others); the plane is fetched by both nt waves (second one hits L2).
     constexpr int S = 32, O = 64;
-    constexpr int kDepth = 2, kMaxKeysPerWave = 64;
+    constexpr int kDepth = DAAM_FIN_KDEPTH, kMaxKeysPerWave = 64;
     __shared__ const void* kbase[2][kMaxKeysPerWave];
     __shared__ __align__(16) float red[2][32 * 64];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: loop bounds and branches stay scalar
     const int n = lane & 31, g = lane >> 5;
     const int nt = wave & 1, kq = wave >> 1;
     DAAM_FT(0);
@@ -349,9 +359,10 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
 
     floatx16 acc[2] = {floatx16{0}, floatx16{0}};             // [mt]
 
-    const int stride = n_chunks * 2;
-    const int first = chunk * 2 + kq;
-    const int nk = first < L.n_keys ? min((L.n_keys - first + stride - 1) / stride, kMaxKeysPerWave) : 0;
+    // this chunk's key range (host-sized, see finalize_chunk_ranges); key lane kq takes every second key of it
+    const int first = L.chunk_begin[chunk] + kq, end = L.chunk_begin[chunk + 1];
+    constexpr int stride = 2;
+    const int nk = first < end ? min((end - first + stride - 1) / stride, kMaxKeysPerWave) : 0;
     if (nt == 0 && lane < nk) kbase[kq][lane] = as_global<FinKey>(L.keys)[first + lane * stride].base;
     __syncthreads();
 
@@ -362,28 +373,30 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
         dst[0] = *as_global<half8>(src);
         dst[1] = *as_global<half8>(src + 16);
     };
+    // Straight-line pipeline: every iteration fetches unconditionally (indices past the end are clamped to the last key:
+    // a harmless re-read), so the loop body has no control flow around its loads and the compiler can wait with COUNTED
+    // vmcnt -- with the fetch inside an `if` it fell back to vmcnt(0), i.e. every iteration also waited for the plane it
+    // had requested one iteration earlier and the prefetch distance collapsed to one.
+    const int last = max(nk - 1, 0);
+    if (nk > 0) {                                             // a wave without keys (fewer keys than key lanes) touches nothing
 #pragma unroll
-    for (int d = 0; d < kDepth; ++d)
-        if (d < nk) fetch(d, pre[d]);
+        for (int d = 0; d < kDepth; ++d) fetch(min(d, last), pre[d]);
+    }
 
     // Issue budget per half plane (tools/ubench_issue.hip, gfx950): an MFMA 32x32x16 holds the matrix pipe for 32 cycles and
     // blocks VALU issue for ~10 of them; VALU of this and of the SIMD's other waves runs under the rest.  10 MFMAs =
     // 326 cycles of matrix pipe; the VALU side is 8 + 8 v_cvt_pk_f16_f32 and 16 v_fma_mix_f32 (5 cycles each) for the
-    // hi / lo split and 32 v_max_f32 (4 cycles) = 288 cycles + 100 blocked: the two pipes are about balanced.
+    // hi / lo split and 32 v_max_i32 (4 cycles) = 288 cycles + 100 blocked: the two pipes are about balanced.
     //   * clamp + accumulate costs ONE v_max per output: pass 2 starts from the running sums (C = acc), so its result is
     //     D = acc + o and  acc + max(o, 0) == max(D, acc)  (fl(acc + o) >= acc exactly when o >= 0);
     //   * lo = T - hi is one mixed-precision FMA straight from the packed fp16 hi (written as T - (float)hi it becomes
     //     v_cvt_f32_f16 + v_sub_f32);
     //   * the max is v_max_i32 on the bit patterns (the sums are never negative): fmaxf() would add a canonicalising v_max.
-    for (int i0 = 0; i0 < nk; i0 += kDepth) {
-#pragma unroll
-      for (int d = 0; d < kDepth; ++d) {
-        const int ki = i0 + d;
-        if (ki >= nk) break;
-        floatx16 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][0], wx[0], floatx16{0}, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pre[d][1], wx[1], c, 0, 0, 0);
+    auto plane_step = [&](int ki, half8 (&p)[2], half8 (&p_next)[2]) {
+        floatx16 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(p[0], wx[0], floatx16{0}, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(p[1], wx[1], c, 0, 0, 0);
 #if !defined(DAAM_FIN_ABLATE) || DAAM_FIN_ABLATE != 1       // experiment 1: no plane fetches after the first kDepth
-        if (ki + kDepth < nk) fetch(ki + kDepth, pre[d]);
+        fetch(min(ki + kDepth, last), p);
 #endif
         half8 bhi[2], blo[2];
 #pragma unroll
@@ -413,8 +426,19 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
             acc[0][v] = fin_max_nonneg(o0[v], acc[0][v]);
             acc[1][v] = fin_max_nonneg(o1[v], acc[1][v]);
         }
-      }
+        // keep the steps of the unrolled body apart: the next step's plane becomes opaque HERE, so its pass 1 cannot be hoisted
+        // to the top of the body (where it would have to wait for a plane fetched only one step earlier); at this point the
+        // plane requested in this step may stay in flight (a counted vmcnt(2))
+        asm volatile("" : "+v"(p_next[0]), "+v"(p_next[1]));
+    };
+    int ki = 0;
+    for (; ki + kDepth <= nk; ki += kDepth) {                 // (never entered with nk == 0: `pre` is then unset and unused)
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) plane_step(ki + d, pre[d], pre[(d + 1) % kDepth]);
     }
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; ++d)                      // remainder (nk not a multiple of kDepth): slots 0 .. in order
+        if (ki + d < nk) plane_step(ki + d, pre[d], pre[(d + 1) % kDepth]);
     DAAM_FT(2);
     // the two key halves of an nt tile meet in LDS; the kq = 0 wave adds the sum into the output
     if (kq == 1) {
@@ -423,6 +447,8 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
     }
     __syncthreads();
     if (kq == 0) {
+        // (a two-level reduction -- per-workgroup slots of a partial buffer + one combine pass instead of these atomics --
+        // measured 6 us SLOWER: the atomics are not what bounds the kernel)
         float* out = L.out + (size_t)tok * O * O + 32 * nt + n;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
@@ -433,7 +459,7 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
     DAAM_FT(3);
 }
 
-__global__ __launch_bounds__(256, 4) void finalize_up32_mfma_kernel(const FinLaunch L)
+__global__ __launch_bounds__(256, DAAM_FIN_WAVES) void finalize_up32_mfma_kernel(const FinLaunch L)
 {
     finalize_up32_mfma_body(L, blockIdx.x, blockIdx.y, gridDim.y);
 }
@@ -510,7 +536,7 @@ struct FinPair {
     int32_t up_blocks, same_gx, same_gy;
 };
 
-__global__ __launch_bounds__(256, 4) void finalize_up32_same_kernel(const FinPair P)
+__global__ __launch_bounds__(256, DAAM_FIN_WAVES) void finalize_up32_same_kernel(const FinPair P)
 {
     const int b = blockIdx.x;
     if (b < P.up_blocks) {

@@ -359,6 +359,74 @@ __global__ __launch_bounds__(256) void word_post_kernel(float* out, int n, const
     out[i] = v;
 }
 
+// ---------------------------------------------------------------------------------------
+// evaluate.compute_iou / compute_ioa (reference daam/evaluate.py:14-35) for a batch of (prediction, truth) pairs.
+// One thread per pixel of the truth mask b; when the shapes differ (the reference tests shape[0] only) the prediction a is
+// resized with the bicubic of F.interpolate (align_corners=False, A = -0.75, border-clamped taps; x on the four source rows,
+// then y) and binarised (a < 1 -> 0, else 1); sums[pair] += {a*b, a, b}, one f32 atomic per wave and quantity -- exact for
+// binary masks (integer sums below 2^24), order-dependent in the last bits for soft ones.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_overlap_kernel(const float* a, int a_h, int a_w, const float* b, int b_h, int b_w,
+                                                           int resize, float* sums)
+{
+#pragma clang fp contract(off)
+    const int pair = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float* ap = a + (size_t)pair * a_h * a_w;
+    float va = 0.f, vb = 0.f;
+    if (i < b_h * b_w) {
+        vb = b[(size_t)pair * b_h * b_w + i];
+        if (!resize) {
+            va = ap[i];
+        } else {
+            const int oy = i / b_w, ox = i - oy * b_w;
+            float wy[4], wx[4];
+            int iy[4], ix[4];
+            {
+                const float sc = (float)a_h / (float)b_h;
+                const float src = sc * ((float)oy + 0.5f) - 0.5f;
+                const float f = floorf(src);
+                cubic_coeffs(src - f, wy);
+                for (int t = 0; t < 4; ++t) iy[t] = min(max((int)f - 1 + t, 0), a_h - 1);
+            }
+            {
+                const float sc = (float)a_w / (float)b_w;
+                const float src = sc * ((float)ox + 0.5f) - 0.5f;
+                const float f = floorf(src);
+                cubic_coeffs(src - f, wx);
+                for (int t = 0; t < 4; ++t) ix[t] = min(max((int)f - 1 + t, 0), a_w - 1);
+            }
+            float rows[4];
+            for (int t = 0; t < 4; ++t) {
+                const float* r = ap + (size_t)iy[t] * a_w;
+                rows[t] = r[ix[0]] * wx[0] + r[ix[1]] * wx[1] + r[ix[2]] * wx[2] + r[ix[3]] * wx[3];
+            }
+            const float v = rows[0] * wy[0] + rows[1] * wy[1] + rows[2] * wy[2] + rows[3] * wy[3];
+            va = v < 1.0f ? 0.0f : 1.0f;                       // a[a < 1] = 0; a[a >= 1] = 1  (evaluate.py:17-18)
+        }
+    }
+    float inter = va * vb, sa = va, sb = vb;
+    for (int off = 32; off > 0; off >>= 1) {
+        inter += __shfl_xor(inter, off, 64);
+        sa += __shfl_xor(sa, off, 64);
+        sb += __shfl_xor(sb, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(sums + 3 * pair + 0, inter);
+        atomicAdd(sums + 3 * pair + 1, sa);
+        atomicAdd(sums + 3 * pair + 2, sb);
+    }
+}
+
+hipError_t launch_mask_overlap(const float* a, int a_h, int a_w, const float* b, int b_h, int b_w, int n, float* sums, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * 3 * (size_t)n, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mask_overlap_kernel, dim3((b_h * b_w + 255) / 256, n), dim3(256), 0, stream, a, a_h, a_w, b, b_h, b_w,
+                       a_h != b_h ? 1 : 0, sums);
+    return hipGetLastError();
+}
+
 // per-launch device tables: pinned host (device-mapped) -> device twin, in stream order on the
 // compute queue (16 bytes per thread; tables are a few tens of KB)
 __global__ __launch_bounds__(256) void upload_kernel(float4* dst, const float4* src, int n16, float4* zero, int z16)

@@ -67,6 +67,8 @@ struct ProbsLaunch {        // daam_tap_probs
     int32_t heads_kept, bh_first, hw, tokens, tiles_per_head, total_wgs, wgs_per_xcd;
 };
 
+constexpr int kFinMaxChunks = 31;
+
 // One selected (layer, head) key of a finalize launch.
 struct FinKey {
     const void* base;       // plane of token 0: [tokens, side, side] follows
@@ -86,6 +88,9 @@ struct FinLaunch {
     float inv_n;
     int32_t max_side;       // largest non-identity side among the keys (LDS carve-up)
     const void* mfma_ops;   // x2 MFMA finalize: [2 nt][64 lanes][6] 16-byte operand pieces (host-built), or NULL
+    // x2 MFMA finalize: chunk c covers the keys [chunk_begin[c], chunk_begin[c + 1]) (even boundaries; its two key lanes take
+    // them alternately); see finalize_chunk_ranges() in daam_api.hip.
+    int16_t chunk_begin[kFinMaxChunks + 1];
 };
 
 // bfloat16 storage type (no arithmetic): values cross to f32 by a shift, back by round-to-nearest-even

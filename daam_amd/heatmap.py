@@ -70,6 +70,11 @@ class WordHeatMap:
             self.plot_overlay(image, **plot_kwargs)
         return out
 
+    def compute_ioa(self, other: 'WordHeatMap') -> float:
+        """reference heatmap.py:95-96."""
+        from .evaluate import compute_ioa
+        return compute_ioa(self.heatmap, other.heatmap)
+
     def plot_overlay(self, image, out_file=None, color_normalize=True, ax=None, **expand_kwargs):
         from .plotting import plot_overlay_heat_map
         plot_overlay_heat_map(image, self.expand_as(image, **expand_kwargs), word=self.word, out_file=out_file,

@@ -12,6 +12,7 @@
  *               (-> token crop is a view; optional per-pixel normalisation = epilogue).
  *   word maps = GlobalHeatMap.compute_word_heat_map + WordHeatMap.expand_as
  *               (daam/heatmap.py:121-123, 77-93)  [SURVEY.md section 8f row f1].
+ *   overlap   = evaluate.compute_iou / compute_ioa (daam/evaluate.py:14-35)  [row f4].
  *
  * Conventions
  *   - extern "C", plain pointers and sizes; no torch types.
@@ -146,6 +147,15 @@ DAAM_API int daam_epilogue_normalize(float* maps, int n_rows, int side, void* st
 DAAM_API int daam_word_heat_map(const float* maps, int side, const int32_t* idx, int n_idx, float* word_map,
                        float* out, int out_h, int out_w, int absolute, float threshold,
                        float* workspace, void* stream);
+
+/* ---- evaluation (next row f4) --------------------------------------------------------------
+ * evaluate.compute_iou / compute_ioa (daam/evaluate.py:14-35) and WordHeatMap.compute_ioa (daam/heatmap.py:95-96) for a
+ * batch of n pairs: a [n, a_h, a_w] (prediction) and b [n, b_h, b_w] (truth), fp32.  When a_h != b_h -- the reference tests
+ * shape[0] only -- a is resized to (b_h, b_w) with the bicubic of F.interpolate and binarised (a < 1 -> 0, else 1); then
+ * sums[i] = { sum(a * b), sum(a), sum(b) }  (sums [n, 3] fp32, overwritten).  The caller forms
+ * IoU = s0 / (s1 + s2 - s0 + 1e-8) and IoA = s0 / (s1 + 1e-8) in fp32. */
+DAAM_API int daam_mask_overlap(const float* a, int a_h, int a_w, const float* b, int b_h, int b_w, int n_pairs, float* sums,
+                               void* stream);
 
 /* ---- misc -------------------------------------------------------------------------------- */
 DAAM_API int daam_abi_version(void);

@@ -276,6 +276,43 @@ def expand_as(word_map: np.ndarray, out_size: int, absolute: bool = False,
 
 
 # --------------------------------------------------------------------------------------
+# f4: evaluate.compute_iou / compute_ioa  (evaluate.py:14-35)
+# --------------------------------------------------------------------------------------
+def _resize_binarise(a: np.ndarray, b_shape) -> np.ndarray:
+    """evaluate.py:15-18: only when the HEIGHTS differ; bicubic to b's (h, w), then a < 1 -> 0, a >= 1 -> 1."""
+    a = a.astype(np.float32)
+    if a.shape[0] == b_shape[0]:
+        return a
+    ih, iw = a.shape
+    oh, ow = b_shape
+    ix, wx = bicubic_taps(iw, ow)
+    iy, wy = bicubic_taps(ih, oh)
+    rows = np.zeros((ih, ow), dtype=np.float32)
+    for t in range(4):
+        rows += a[:, ix[:, t]] * wx[:, t]
+    out = np.zeros((oh, ow), dtype=np.float32)
+    for t in range(4):
+        out += rows[iy[:, t], :] * wy[:, t][:, None]
+    return np.where(out < 1, np.float32(0), np.float32(1)).astype(np.float32)
+
+
+def mask_overlap(a: np.ndarray, b: np.ndarray):
+    a = _resize_binarise(a, b.shape)
+    b = b.astype(np.float32)
+    return np.float32((a * b).sum(dtype=np.float32)), np.float32(a.sum(dtype=np.float32)), np.float32(b.sum(dtype=np.float32))
+
+
+def compute_iou(a: np.ndarray, b: np.ndarray) -> float:
+    inter, sa, sb = mask_overlap(a, b)
+    return float(inter / (sa + sb - inter + np.float32(1e-8)))
+
+
+def compute_ioa(a: np.ndarray, b: np.ndarray) -> float:
+    inter, sa, _ = mask_overlap(a, b)
+    return float(inter / (sa + np.float32(1e-8)))
+
+
+# --------------------------------------------------------------------------------------
 # a1: UNetCrossAttentionLocator.locate  (hook.py:95-127)
 # --------------------------------------------------------------------------------------
 def locate(unet, restrict=None, locate_middle_block: bool = False):

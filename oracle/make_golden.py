@@ -216,14 +216,54 @@ def run_case(name, spec, daam):
           f'{os.path.getsize(path) / 1e6:.2f} MB')
 
 
+def evaluate_inputs():
+    """Seeded (prediction, truth) pairs for the reference's compute_iou / compute_ioa (evaluate.py:14-35): binary blobs
+    upscaled x8 and x2 (every bicubic weight of a power-of-two scale is exact in fp32, so the `>= 1` threshold is
+    well-defined), a soft prediction upscaled to a NON-square truth, and same-height pairs (no resize, a used as is)."""
+    g = torch.Generator().manual_seed(77)
+
+    def blobs(n, h, w, p):
+        x = torch.rand(n, 1, h // 4, w // 4, generator=g)
+        x = torch.nn.functional.interpolate(x, size=(h, w), mode='nearest')[:, 0]
+        return (x > p).float()
+    pairs = {
+        'binary_64_to_512': (blobs(3, 64, 64, 0.5), blobs(3, 512, 512, 0.6)),
+        'binary_32_to_64': (blobs(4, 32, 32, 0.4), blobs(4, 64, 64, 0.5)),
+        'soft_48x64_to_96x160': (torch.rand(3, 48, 64, generator=g) * 2.0, blobs(3, 96, 160, 0.5)),
+        'same_binary_64': (blobs(3, 64, 64, 0.5), blobs(3, 64, 64, 0.5)),
+        'same_soft_64': (torch.rand(3, 64, 64, generator=g), blobs(3, 64, 64, 0.3)),
+    }
+    return pairs
+
+
+def run_evaluate(daam):
+    """tests/golden/evaluate.npz: the unmodified reference's compute_iou / compute_ioa on evaluate_inputs()."""
+    ev = sys.modules['daam.evaluate']
+    out = {}
+    for name, (a, b) in evaluate_inputs().items():
+        out[f'{name}_a'] = a.numpy()
+        out[f'{name}_b'] = b.numpy()
+        out[f'{name}_iou'] = np.asarray([ev.compute_iou(a[i].clone(), b[i].clone()) for i in range(a.shape[0])], dtype=np.float64)
+        out[f'{name}_ioa'] = np.asarray([ev.compute_ioa(a[i].clone(), b[i].clone()) for i in range(a.shape[0])], dtype=np.float64)
+    out['names'] = np.asarray(json.dumps(list(evaluate_inputs())))
+    out['meta'] = np.asarray(json.dumps(dict(reference='castorini/daam v0.2.0 daam/evaluate.py, executed unmodified',
+                                             torch=torch.__version__)))
+    path = os.path.join(OUT_DIR, 'evaluate.npz')
+    np.savez_compressed(path, **out)
+    print(f'evaluate: {len(evaluate_inputs())} groups, {os.path.getsize(path) / 1e6:.2f} MB')
+
+
 def main(argv):
     warnings.filterwarnings('ignore')
     torch.set_num_threads(os.cpu_count() or 1)
     daam, _ = fd.import_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
-    names = argv or list(CASES)
+    names = argv or list(CASES) + ['evaluate']
     for n in names:
-        run_case(n, CASES[n], daam)
+        if n == 'evaluate':
+            run_evaluate(daam)
+        else:
+            run_case(n, CASES[n], daam)
 
 
 if __name__ == '__main__':

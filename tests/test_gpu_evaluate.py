@@ -1,0 +1,72 @@
+"""``compute_iou`` / ``compute_ioa`` (reference daam/evaluate.py:14-35) and
+``WordHeatMap.compute_ioa`` (daam/heatmap.py:95-96) on the HIP kernel ``daam_mask_overlap``, against the golden results of
+the unmodified reference (tests/golden/evaluate.npz) and the numpy oracle.  Run with ``-m gpu`` on an MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle import heatmap_oracle as ho
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _golden():
+    z = np.load(os.path.join(GOLDEN_DIR, 'evaluate.npz'))
+    return z, json.loads(str(z['names']))
+
+
+def test_iou_ioa_match_reference_golden():
+    import daam_amd
+    from daam_amd.evaluate import compute_ioa_batch, compute_iou_batch, mask_overlap
+    z, names = _golden()
+    for name in names:
+        a, b = torch.from_numpy(z[f'{name}_a']).to(DEV), torch.from_numpy(z[f'{name}_b']).to(DEV)
+        # power-of-two upscales of binary masks and same-size binary masks: every sum is an exact integer -> the fp32 ratio
+        # is the reference's to the last bit; soft predictions: the bicubic value next to the threshold / the summation order
+        # of non-integer sums may differ in the last place
+        tol = 0.0 if 'binary' in name else 1e-6
+        iou, ioa = compute_iou_batch(a, b), compute_ioa_batch(a, b)
+        np.testing.assert_allclose(iou, z[f'{name}_iou'].astype(np.float32), rtol=0, atol=tol, err_msg=name)
+        np.testing.assert_allclose(ioa, z[f'{name}_ioa'].astype(np.float32), rtol=0, atol=tol, err_msg=name)
+        # one pair at a time = the reference's call signature
+        for i in range(a.shape[0]):
+            assert abs(daam_amd.compute_iou(a[i], b[i]) - float(z[f'{name}_iou'][i])) <= max(tol, 1e-7)
+            assert abs(daam_amd.compute_ioa(a[i], b[i]) - float(z[f'{name}_ioa'][i])) <= max(tol, 1e-7)
+        # the three sums against the oracle
+        sums = mask_overlap(a, b).cpu().numpy()
+        for i in range(a.shape[0]):
+            want = ho.mask_overlap(z[f'{name}_a'][i], z[f'{name}_b'][i])
+            np.testing.assert_allclose(sums[i], np.asarray(want), rtol=2e-6 if 'soft' in name else 0, atol=0)
+
+
+@pytest.mark.parametrize('shape', [((64, 64), (512, 512)), ((64, 64), (1024, 1024)), ((17, 23), (40, 31)), ((96, 96), (64, 64))])
+def test_mask_overlap_vs_oracle_random_shapes(shape):
+    """Odd sizes, non-square masks, down-scaling: the sums against the oracle; pixels whose bicubic value lies within 1e-5 of the
+    threshold may fall on either side (the reference itself is platform-dependent there)."""
+    from daam_amd.evaluate import mask_overlap
+    (ah, aw), (bh, bw) = shape
+    rng = np.random.default_rng(ah * 1000 + bw)
+    a = (rng.random((2, ah, aw)) * 2.0).astype(np.float32)
+    b = (rng.random((2, bh, bw)) > 0.5).astype(np.float32)
+    got = mask_overlap(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).cpu().numpy()
+    for i in range(2):
+        want = np.asarray(ho.mask_overlap(a[i], b[i]))
+        assert np.abs(got[i] - want).max() <= 1e-4 * bh * bw + 1e-3, (shape, got[i], want)
+
+
+def test_word_heat_map_compute_ioa_and_errors():
+    import daam_amd
+    from daam_amd.heatmap import WordHeatMap
+    rng = np.random.default_rng(3)
+    x, y = rng.random((64, 64)).astype(np.float32), rng.random((64, 64)).astype(np.float32)
+    got = WordHeatMap(torch.from_numpy(x).to(DEV), 'a').compute_ioa(WordHeatMap(torch.from_numpy(y).to(DEV), 'b'))
+    assert abs(got - ho.compute_ioa(x, y)) <= 1e-6                      # same shapes: no resize, no binarisation (evaluate.py:27)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        daam_amd.compute_iou(torch.zeros(4, 4), torch.zeros(4, 4))
+    with pytest.raises(daam_amd._native.DaamError):
+        daam_amd.compute_iou(torch.zeros(8, 4, device=DEV), torch.zeros(8, 6, device=DEV))   # same height, other width

@@ -96,7 +96,7 @@ def test_full_size_layer_50_steps_vs_oracle(name, heads, side, d, steps, latent_
     # ONE layer = `heads` keys: a key whose sum differs by one fp16 ulp (2^-5 for sums in [32, 64)) moves this mean by
     # ulp / heads; the north_star's 1e-3 is a statement about the mean over all 1100 keys of a generation (there the same
     # key moves it by 3e-5: tests/test_gpu_integration.py measures 1e-5 on the full stack)
-    tol = max(1e-3, float(_ulp16(np.asarray(want.max()))) / heads)
+    tol = max(1e-3, 1.01 * float(_ulp16(np.asarray(want.max()))) / heads)          # + fp32 rounding of the mean itself
     assert np.abs(gm - ref).max() <= tol, f'{name}: global map {np.abs(gm - ref).max()} > {tol}'
     eng.close()
 

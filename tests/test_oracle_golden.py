@@ -77,3 +77,18 @@ def test_no_maps_errors():
         ho.global_heat_map(raw, 4096)
     with pytest.raises(RuntimeError, match='given parameters'):
         ho.global_heat_map(raw, 4096, head_idx=3)
+
+
+def test_oracle_iou_ioa_match_reference():
+    """oracle compute_iou / compute_ioa (evaluate.py:14-35 restated) against the reference's own results
+    (tests/golden/evaluate.npz, made by oracle/make_golden.py from the unmodified daam/evaluate.py)."""
+    import os
+    from conftest import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'evaluate.npz'))
+    for name in json.loads(str(z['names'])):
+        a, b = z[f'{name}_a'], z[f'{name}_b']
+        iou = np.asarray([ho.compute_iou(a[i], b[i]) for i in range(len(a))])
+        ioa = np.asarray([ho.compute_ioa(a[i], b[i]) for i in range(len(a))])
+        tol = 0.0 if 'binary' in name else 2e-7          # binary masks: integer sums, exact in any order
+        np.testing.assert_allclose(iou, z[f'{name}_iou'], rtol=0, atol=tol, err_msg=name)
+        np.testing.assert_allclose(ioa, z[f'{name}_ioa'], rtol=0, atol=tol, err_msg=name)

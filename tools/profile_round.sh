@@ -1,18 +1,21 @@
 #!/bin/bash
-# Round profile on the GPU box (run through gpurun from the repo root):
-#   kernel-trace stats of the default bench, three separate PMC passes, condensed into profiles/.
-# usage: tools/profile_round.sh <tag> <traffic key>      e.g.  tools/profile_round.sh r01 sdxl1024:defer50:exact
+# Round profile on the GPU box (run through gpurun from the repo root): kernel-trace stats of the bench, separate PMC passes
+# (SQ issue counters; MFMA counters; FETCH_SIZE; WRITE_SIZE -- never combined with trace domains other than --kernel-trace),
+# condensed by tools/summarize_profiles.py into gpurun_out/profiles_<tag>/ (copy what is to be judged into profiles/).
+# usage: tools/profile_round.sh <tag> [workload [denoise steps [defer]]]     e.g.  tools/profile_round.sh r02 sdxl1024 50 50
 set -u
-TAG=${1:-r01}; KEY=${2:-sdxl1024:defer50:exact}
-R=$(pwd); O=$R/gpurun_out/prof_$TAG
+TAG=${1:-r02}; WL=${2:-sdxl1024}; DS=${3:-50}; DEFER=${4:-$DS}
+KEY=$WL:defer$DEFER:exact
+R=$(pwd); O=$R/gpurun_out/prof_${TAG}_$WL
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-baselines --steps 40 --warmup 2"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH > $O/stats.log 2>&1
-PM="python $R/bench.py --no-baselines --steps 6 --warmup 2"
+ARGS="--no-baselines --no-integrated --workload $WL --denoise-steps $DS"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py $ARGS --steps 30 --warmup 2 > $O/stats.log 2>&1
+PM="python $R/bench.py $ARGS --steps 5 --warmup 2"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- $PM > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU --output-format csv -d $O/pmc_mfma -- $PM > $O/pmc_mfma.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $PM > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $PM > $O/pmc_write.log 2>&1
 cd $R
-python tools/summarize_profiles.py --tag $TAG --stats $O/stats --pmc $O/pmc_sq $O/pmc_fetch $O/pmc_write --key $KEY --out gpurun_out/profiles_$TAG
+python tools/summarize_profiles.py --tag ${TAG}_$WL --stats $O/stats --pmc $O/pmc_sq $O/pmc_mfma $O/pmc_fetch $O/pmc_write --key $KEY --out gpurun_out/profiles_$TAG
 for f in $O/*.log; do tail -n 2 $f | cut -c1-200; done
-rm -rf $O/stats $O/pmc_sq $O/pmc_fetch $O/pmc_write      # raw traces are > 64 MiB: only the summaries travel back
+rm -rf $O/stats $O/pmc_sq $O/pmc_mfma $O/pmc_fetch $O/pmc_write      # raw traces are > 64 MiB: only the summaries travel back

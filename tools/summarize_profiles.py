@@ -89,6 +89,45 @@ def main():
             traffic[a.key] = rec
             json.dump(traffic, open(tpath, 'w'), indent=1, sort_keys=True)
             print('wrote', tpath, rec)
+        # what bench.py reads for its rooflines (profiles/<tag>_counters.json), tied to the kernel sources by their fingerprint
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from daam_amd.build import csrc_sha
+        cpath = os.path.join(a.out, a.tag.split('_')[0] + '_counters.json')      # one file per round, one entry per workload
+        counters = json.load(open(cpath)) if os.path.exists(cpath) else {}
+        if counters.get('csrc_sha') != csrc_sha():
+            counters = dict(csrc_sha=csrc_sha(), workloads={},
+                            method='rocprofv3 --pmc passes of `python bench.py --workload W` (tools/profile_round.sh); per launch: '
+                                   'upper-median over the launches of a kernel; *_per_simd = counter / 1024 SIMDs; '
+                                   'VALU busy cycles = SQ_ACTIVE_INST_VALU (quad-cycles) x 4; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024')
+        w = dict(rec) if rec else {}
+        w.pop('method', None)
+
+        def upper_median(v):
+            v = sorted(v)
+            return statistics.median(v[len(v) // 2:])
+        tap_names = [k for k in ('tap_d64_kernel', 'tap_mfma_kernel') if k in pmc and 'SQ_ACTIVE_INST_VALU' in pmc[k]]
+        if tap_names:
+            # a flush may run several tap kernels side by side (SD-v1.5): their work adds up on the same SIMDs
+            w['tap_valu_busy_cycles_per_simd'] = round(sum(upper_median(pmc[k]['SQ_ACTIVE_INST_VALU']) for k in tap_names) * 4 / 1024, 1)
+            w['tap_valu_insts_per_simd'] = round(sum(upper_median(pmc[k]['SQ_INSTS_VALU']) for k in tap_names) / 1024, 1)
+            if all('SQ_INSTS_MFMA' in pmc[k] for k in tap_names):
+                w['tap_mfma_per_simd'] = round(sum(upper_median(pmc[k]['SQ_INSTS_MFMA']) for k in tap_names) / 1024, 1)
+            if all('SQ_VALU_MFMA_BUSY_CYCLES' in pmc[k] for k in tap_names):
+                w['tap_mfma_busy_cycles_per_simd'] = round(sum(upper_median(pmc[k]['SQ_VALU_MFMA_BUSY_CYCLES']) for k in tap_names) / 1024, 1)
+        fin_names = [k for k in ('finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_same_kernel', 'finalize_up_kernel',
+                                 'finalize_kernel') if k in pmc and 'SQ_ACTIVE_INST_VALU' in pmc[k]]
+        if fin_names:
+            w['finalize_valu_busy_cycles_per_simd'] = round(sum(upper_median(pmc[k]['SQ_ACTIVE_INST_VALU']) for k in fin_names) * 4 / 1024, 1)
+            w['finalize_mfma_per_simd'] = round(sum(upper_median(pmc[k].get('SQ_INSTS_MFMA', [0])) for k in fin_names) / 1024, 1)
+            w['finalize_kernels'] = fin_names
+            fe = sum(upper_median(pmc[k]['FETCH_SIZE']) for k in fin_names if 'FETCH_SIZE' in pmc[k])
+            wr = sum(upper_median(pmc[k]['WRITE_SIZE']) for k in fin_names if 'WRITE_SIZE' in pmc[k])
+            if fe:
+                w['finalize_bytes_per_launch'] = int((2 * fe + wr) * 1024)
+        counters['workloads'][a.key] = w
+        json.dump(counters, open(cpath, 'w'), indent=1, sort_keys=True)
+        print('wrote', cpath, w)
 
 
 if __name__ == '__main__':
