@@ -22,7 +22,7 @@ bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t 
 int tap_mfma_tile_pixels();
 int tap_mfma_ksteps(int head_dim);
 int tap_mfma_max_steps();
-hipError_t launch_tap_d64(const TapLaunch&, int in_dtype, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
+hipError_t launch_tap_d64(const TapLaunch&, int in_dtype, int acc_dtype, int fast_exp, int full64, hipStream_t, int*, int*);
 bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                        const void* q, const void* k);
 
@@ -33,6 +33,8 @@ hipError_t launch_finalize_up32_same(const FinLaunch& up, const FinLaunch& same,
 hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
 hipError_t launch_finalize_up(const FinLaunch&, int side, int, int mfma_ok, hipStream_t, int*);
 bool finalize_up_supported(int side, int out_side);
+bool finalize_down2_supported(int side, int out_side);
+hipError_t launch_finalize_down2(const FinLaunch&, int, hipStream_t, int*);
 hipError_t launch_normalize(float*, int, int, hipStream_t);
 hipError_t launch_mask_overlap(const float*, int, int, const float*, int, int, int, float*, hipStream_t);
 hipError_t launch_clock_monitor(unsigned long long* samples, int n_samples, int period_us, hipStream_t);
@@ -563,7 +565,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     L.wgs_per_xcd = (L.total_wgs + 7) / 8;
     c->last_block[0] = 256;
     const int kd1 = mfma ? mfma_kind(c, *d, q, k) : 0;
-    hipError_t e = (kd1 == 65 || kd1 == 66) ? launch_tap_d64(L, d->in_dtype, c->acc_dtype, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+    hipError_t e = (kd1 == 65 || kd1 == 66) ? launch_tap_d64(L, d->in_dtype, c->acc_dtype, c->fast_exp && d->round_logits, d->head_dim == 64, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                         : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
                                              &c->last_grid[0], &c->last_lds[0]);
@@ -666,7 +668,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     int rc = 0;
     int grid_total = 0;
     // pass 1: the tables of every kernel kind -> ring -> device (all on the caller's stream)
-    struct Prepared { int kd; TapLaunch L; int max_d; int all_round; size_t ring_begin, ring_end; };
+    struct Prepared { int kd; TapLaunch L; int max_d; int min_d; int all_round; size_t ring_begin, ring_end; };
     std::vector<Prepared> prepared;
     for (int kd : kinds) {
         size_t n_layers = 0, n_ptrs = 0;
@@ -684,7 +686,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         if (e != hipSuccess) { rc = fail((int)e, "upload ring: %s", hipGetErrorString(e)); break; }
         TapLayer* hl = reinterpret_cast<TapLayer*>(c->ring.host + off);
         TapPtr* hp = reinterpret_cast<TapPtr*>(c->ring.host + off + bytes_layers);
-        int wg = 0, ptr = 0, max_d = 0, all_round = 1;
+        int wg = 0, ptr = 0, max_d = 0, min_d = 1 << 30, all_round = 1;
         size_t j = 0;
         for (size_t i = 0; i < order.size(); ++i) {
             if (kind[i] != kd) continue;
@@ -696,6 +698,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             for (auto* p : v) { hp[ptr].q = p->q; hp[ptr].k = p->k; ++ptr; }
             wg += hl[j].heads_kept * hl[j].tiles_per_head;
             max_d = std::max(max_d, v[0]->d.head_dim);
+            min_d = std::min(min_d, v[0]->d.head_dim);
             all_round = all_round && v[0]->d.round_logits;
             ++j;
         }
@@ -711,6 +714,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         pr.L.total_wgs = wg;
         pr.L.wgs_per_xcd = (wg + 7) / 8;
         pr.max_d = max_d;
+        pr.min_d = min_d;
         pr.all_round = all_round;
         pr.ring_begin = c->ring.cur_begin;
         pr.ring_end = c->ring.cur_end;
@@ -754,7 +758,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             if (hipStreamWaitEvent(ks, c->aux_fork, 0) != hipSuccess) { rc = fail(DAAM_E_STATE, "stream fork failed"); break; }
         }
         int grid = 0;
-        hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
+        hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, ks, &grid, &c->last_lds[0])
                      : pr.kd ? launch_tap_mfma(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
                              : launch_tap_generic(pr.L, in_dtype, c->acc_dtype, pr.max_d, ks, &grid, &c->last_lds[0]);
         grid_total += grid;
@@ -838,8 +842,9 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             int zrc = ensure_zeroed(l, (hipStream_t)stream);
             if (zrc) return zrc;
         }
-    // classes: 0 = same size (clamp + mean), 1 = x2 (32 -> 64), 2 = x4 (16 -> 64), 3 = general kernel
-    std::vector<FinKey> keys[4];
+    // classes: 0 = same size (clamp + mean), 1 = x2 (32 -> 64), 2 = x4 (16 -> 64), 3 = general kernel, 4 = x0.5 (128 -> 64)
+    constexpr int kClasses = 5;
+    std::vector<FinKey> keys[kClasses];
     int pos = 0, max_side = 0, total = 0;
     for (int i = 0; i < c->max_layers; ++i) {
         const Layer& l = c->layers[i];
@@ -854,6 +859,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             if (!c->force_generic) {
                 if (l.tab < 0 && (l.hw % 8) == 0) cls = 0;
                 else if (l.tab >= 0 && finalize_up_supported(l.side, c->out_side)) cls = l.side == 32 ? 1 : 2;
+                else if (l.tab >= 0 && finalize_down2_supported(l.side, c->out_side)) cls = 4;
             }
             if (cls == 3 && l.tab >= 0) max_side = std::max(max_side, l.side);
             keys[cls].push_back(k);
@@ -878,9 +884,9 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     c->last_lds[1] = 0;
     static const int env_chunks = getenv("DAAM_FIN_CHUNKS") ? atoi(getenv("DAAM_FIN_CHUNKS")) : 0;
     // build the launch descriptor of every non-empty class first
-    FinLaunch launches[4];
-    bool have[4] = {false, false, false, false};
-    for (int cls = 0; cls < 4; ++cls) {
+    FinLaunch launches[kClasses];
+    bool have[kClasses] = {false, false, false, false, false};
+    for (int cls = 0; cls < kClasses; ++cls) {
         const int n = (int)keys[cls].size();
         if (n == 0) continue;
         FinLaunch& L = launches[cls];
@@ -905,7 +911,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             // more pays the per-workgroup reduction + atomics too often.
             const int want = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
             L.n_chunks = std::max(std::max(1, std::min((n + 3) / 4, want)), (n + 127) / 128);   // <= 64 keys per wave (2 or 4 key lanes per workgroup)
-            L.n_chunks = std::min(L.n_chunks, kFinMaxChunks);
+            if (cls == 1) L.n_chunks = std::min(L.n_chunks, kFinMaxChunks);
         }
         memset(L.chunk_begin, 0, sizeof L.chunk_begin);
         if (cls == 1) finalize_chunk_ranges(n, L.n_chunks, &L);
@@ -930,7 +936,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             return fail((int)ce, "table upload: %s", hipGetErrorString(ce));
         }
     }
-    for (int cls = 0; cls < 4; ++cls) {
+    for (int cls = 0; cls < kClasses; ++cls) {
         if (!have[cls] || (paired && cls == 0)) continue;
         const FinLaunch& L = launches[cls];
         int grid = 0, lds = 0;
@@ -938,6 +944,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         if (cls == 1 && paired) e = launch_finalize_up32_same(L, launches[0], s, &grid);
         else if (cls == 0) e = launch_finalize_same(L, c->acc_dtype, s, &grid);
         else if (cls == 3) e = launch_finalize(L, c->acc_dtype, s, &grid, &lds);
+        else if (cls == 4) e = launch_finalize_down2(L, c->acc_dtype, s, &grid);
         else e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, c->tab_fp16_exact[keys[cls][0].tab] && !c->no_mfma_finalize, s, &grid);
         if (e != hipSuccess) {
             (void)c->ring.release(s);                      // the table region is reusable once whatever did launch has run

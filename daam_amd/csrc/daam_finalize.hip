@@ -323,6 +323,107 @@ __device__ __forceinline__ floatx16 fin_mfma_from(const half8& a, const half8& b
 #endif
 }
 
+// ---------------------------------------------------------------------------------------
+// x0.5 (128 -> 64: the 128x128 layers of SDXL at 2048 px, factor 0).  Pure streaming: a 32 KB plane is read once, row by row.
+// One WAVE walks a strided list of keys for one token; lane = output column ox and reads the dword (two 16-bit elements) /
+// the float2 that holds source columns 2ox, 2ox + 1 of every source row -- 256 contiguous bytes per wave and row; the outer taps
+// 2ox - 1 and 2ox + 2 are the neighbour lanes' inner ones, fetched with one wave-shift DPP move each (the border lanes keep
+// their own value = torch's index clamp).  A x0.5 bicubic has t = 0.5 everywhere: the same four weights (w0, w1, w1, w0) for
+// every output, so  h = w1 (x0 + x1) + w0 (xl + xr)  per source row and  out = w1 (h[2oy] + h[2oy+1]) + w0 (h[2oy-1] + h[2oy+2])
+// on a 4-deep window of row results; clamp, accumulate in the lane's 64 output registers.  Everything is unrolled at compile
+// time (static register indices); rows are fetched 16 at a time, one batch ahead (across keys too).
+// ---------------------------------------------------------------------------------------
+template <typename T> struct Pair2;
+template <> struct Pair2<_Float16> {
+    using Raw = unsigned;
+    static __device__ __forceinline__ void cvt(Raw r, float& a, float& b) {
+        const half2v h = __builtin_bit_cast(half2v, r);
+        a = (float)h[0]; b = (float)h[1];
+    }
+};
+template <> struct Pair2<bf16_t> {
+    using Raw = unsigned;
+    static __device__ __forceinline__ void cvt(Raw r, float& a, float& b) { a = __uint_as_float(r << 16); b = __uint_as_float(r & 0xffff0000u); }
+};
+template <> struct Pair2<float> {
+    using Raw = float2v;
+    static __device__ __forceinline__ void cvt(Raw r, float& a, float& b) { a = r[0]; b = r[1]; }
+};
+
+template <typename ACC_T>
+__global__ __launch_bounds__(256) void finalize_down2_kernel(const FinLaunch L)
+{
+    constexpr int O = 64, S = 128, RB = 16, NB = S / RB;
+    using P2 = Pair2<ACC_T>;
+    using Raw = typename P2::Raw;
+    __shared__ __align__(16) float red[2 * O * O];
+    constexpr int kMaxKeysPerWave = 64;
+    __shared__ const void* kbase[4][kMaxKeysPerWave];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = blockIdx.x;
+    const float* tw = L.tab_w + (size_t)L.keys[0].tab * O * 4;            // one map size per launch; t = 0.5 for every output
+    const float w0 = tw[0], w1 = tw[1];
+    // border clamp folded into the weights: lane 0's tap at column -1 is its own x0, lane 63's tap at column 128 its own x1
+    const float w1a = lane == 0 ? w1 + w0 : w1, w1b = lane == 63 ? w1 + w0 : w1;
+
+    float acc[O];
+#pragma unroll
+    for (int i = 0; i < O; ++i) acc[i] = 0.f;
+
+    const int stride = gridDim.y * 4;
+    const int first = blockIdx.y * 4 + wave;
+    const int nk = first < L.n_keys ? min((L.n_keys - first + stride - 1) / stride, kMaxKeysPerWave) : 0;
+    if (lane < nk) kbase[wave][lane] = as_global<FinKey>(L.keys)[first + lane * stride].base;
+    __builtin_amdgcn_wave_barrier();
+
+    auto row_ptr = [&](int ki) {
+        return reinterpret_cast<const ACC_T*>(kbase[wave][ki]) + (size_t)tok * S * S + 2 * lane;
+    };
+    auto fetch = [&](const ACC_T* src, int b, Raw (&dst)[RB]) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) dst[r] = *as_global<Raw>(src + (size_t)(b * RB + r) * S);
+    };
+    if (nk > 0) {
+        Raw buf[2][RB];
+        fetch(row_ptr(0), 0, buf[0]);
+        for (int ki = 0; ki < nk; ++ki) {
+            const ACC_T* src = row_ptr(ki);
+            const ACC_T* nxt = row_ptr(min(ki + 1, nk - 1));              // the last key re-reads its first batch (harmless)
+            float hw[4] = {0.f, 0.f, 0.f, 0.f};                            // h[row - 3 .. row]
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (b + 1 < NB) fetch(src, b + 1, buf[(b + 1) & 1]);
+                else fetch(nxt, 0, buf[(b + 1) & 1]);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    const int row = b * RB + r;
+                    float x0, x1;
+                    P2::cvt(buf[b & 1][r], x0, x1);
+                    // columns 2ox - 1 / 2ox + 2 = lane - 1's x1 / lane + 1's x0: DPP wave shift right / left by one lane with
+                    // bound_ctrl (lanes 0 / 63 receive 0; their clamped border tap sits in w1a / w1b)
+                    const float xl = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x1), 0x138, 0xf, 0xf, true));
+                    const float xr = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x0), 0x130, 0xf, 0xf, true));
+                    const float h = __builtin_fmaf(w1a, x0, __builtin_fmaf(w1b, x1, w0 * (xl + xr)));
+                    hw[0] = hw[1]; hw[1] = hw[2]; hw[2] = hw[3]; hw[3] = h;
+                    if (row == 0) hw[2] = h;                               // h[-1] := h[0]  (rows above the plane clamp to row 0)
+                    if (row >= 2 && (row & 1) == 0) {                      // h[row - 3 .. row] = h[2oy - 1 .. 2oy + 2], oy = row / 2 - 1
+                        const float v = __builtin_fmaf(w1, hw[1] + hw[2], w0 * (hw[0] + hw[3]));
+                        acc[row / 2 - 1] += fmaxf(v, 0.f);
+                    }
+                }
+            }
+            // oy = 63: h[125], h[126], h[127], h[128] := h[127]
+            const float v = __builtin_fmaf(w1, hw[2] + hw[3], w0 * (hw[1] + hw[3]));
+            acc[O - 1] += fmaxf(v, 0.f);
+        }
+    }
+    auto get = [&](int oy) -> float { return acc[oy]; };
+    auto add = [&](int oy, float v) { acc[oy] += v; };
+    wg_reduce_flush(red, wave, get, add, [&](int i) { return i * O + lane; }, L.out + (size_t)tok * O * O, L.inv_n);
+}
+
 // tunables of the x2 MFMA kernel (overridable for A/B builds): planes prefetched ahead per wave, waves per SIMD the register
 // allocator must leave room for
 #ifndef DAAM_FIN_KDEPTH
@@ -587,6 +688,17 @@ hipError_t launch_finalize_same(const FinLaunch& L, int acc_dtype, hipStream_t s
 }
 
 bool finalize_up_supported(int side, int out_side) { return out_side == 64 && (side == 32 || side == 16); }
+bool finalize_down2_supported(int side, int out_side) { return out_side == 64 && side == 128; }
+
+hipError_t launch_finalize_down2(const FinLaunch& L, int acc_dtype, hipStream_t stream, int* grid_out)
+{
+    dim3 grid(L.tokens, L.n_chunks);
+    *grid_out = grid.x * grid.y;
+    if (acc_dtype == 0) hipLaunchKernelGGL((finalize_down2_kernel<_Float16>), grid, dim3(256), 0, stream, L);
+    else if (acc_dtype == 2) hipLaunchKernelGGL((finalize_down2_kernel<bf16_t>), grid, dim3(256), 0, stream, L);
+    else hipLaunchKernelGGL((finalize_down2_kernel<float>), grid, dim3(256), 0, stream, L);
+    return hipGetLastError();
+}
 
 hipError_t launch_finalize_up(const FinLaunch& L, int side, int acc_dtype, int mfma_ok, hipStream_t stream, int* grid_out)
 {

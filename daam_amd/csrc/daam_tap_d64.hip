@@ -254,7 +254,9 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
     }
 }
 
-template <typename IN, typename ACC_T, bool FAST_EXP>
+// FULL64: every layer of the launch has head_dim == 64 (SDXL): the zero-padding selects of the head_dim < 64 case (8 VALU per
+// wave-step) are compiled out
+template <typename IN, typename ACC_T, bool FAST_EXP, bool FULL64>
 __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
 {
     constexpr int KCH = (kTok * 8 + 255) / 256;               // 16-B K pieces per thread per step (3)
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     // K pieces past it are never written (the buffers are zeroed once), the lanes' Q pieces past it are
     // fetched from a valid address and cleared before the MFMAs.
     const int d = lay.head_dim;
-    const bool partial = d < 64;                              // wave-uniform
+    const bool partial = !FULL64 && d < 64;                   // wave-uniform
     if (partial) {
         for (int i = tid; i < 2 * kD64KBuf / 16; i += 256)
             *reinterpret_cast<float4v*>(kbuf + i * 16) = float4v{0, 0, 0, 0};
@@ -444,36 +446,42 @@ bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, i
     return ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
 }
 
-template <typename IN, typename ACC_T, bool FAST>
-static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out)
+template <typename IN, typename ACC_T, bool FAST, bool FULL64>
+static hipError_t launch_d64_k(const TapLaunch& L, hipStream_t stream, int grid, size_t lds)
 {
-    const size_t lds = tap_d64_lds_bytes<ACC_T>();
-    *lds_out = lds;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_d64_kernel<IN, ACC_T, FAST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_d64_kernel<IN, ACC_T, FAST, FULL64>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((tap_d64_kernel<IN, ACC_T, FAST>), dim3(grid), dim3(256), lds, stream, L);
+    hipLaunchKernelGGL((tap_d64_kernel<IN, ACC_T, FAST, FULL64>), dim3(grid), dim3(256), lds, stream, L);
     return hipGetLastError();
 }
 
-hipError_t launch_tap_d64(const TapLaunch& L, int in_dtype, int acc_dtype, int fast_exp, hipStream_t stream, int* grid_out, int* lds_out)
+template <typename IN, typename ACC_T, bool FAST>
+static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out, bool full64)
+{
+    const size_t lds = tap_d64_lds_bytes<ACC_T>();
+    *lds_out = lds;
+    return full64 ? launch_d64_k<IN, ACC_T, FAST, true>(L, stream, grid, lds) : launch_d64_k<IN, ACC_T, FAST, false>(L, stream, grid, lds);
+}
+
+hipError_t launch_tap_d64(const TapLaunch& L, int in_dtype, int acc_dtype, int fast_exp, int full64, hipStream_t stream, int* grid_out, int* lds_out)
 {
     const int grid = L.wgs_per_xcd * 8;
     *grid_out = grid;
     size_t lds = 0;
     hipError_t e;
     if (in_dtype == 2) {                                       // bf16 pipeline: one softmax flavour
-        if (acc_dtype == 2) e = launch_d64<InBF16, bf16_t, true>(L, stream, grid, &lds);
-        else if (acc_dtype == 1) e = launch_d64<InBF16, float, true>(L, stream, grid, &lds);
+        if (acc_dtype == 2) e = launch_d64<InBF16, bf16_t, true>(L, stream, grid, &lds, full64 != 0);
+        else if (acc_dtype == 1) e = launch_d64<InBF16, float, true>(L, stream, grid, &lds, full64 != 0);
         else return hipErrorInvalidValue;
     } else if (acc_dtype != 0 && acc_dtype != 1) {
         return hipErrorInvalidValue;
     } else if (fast_exp) {
-        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, true>(L, stream, grid, &lds) : launch_d64<InF16, float, true>(L, stream, grid, &lds);
+        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, true>(L, stream, grid, &lds, full64 != 0) : launch_d64<InF16, float, true>(L, stream, grid, &lds, full64 != 0);
     } else {
-        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, false>(L, stream, grid, &lds) : launch_d64<InF16, float, false>(L, stream, grid, &lds);
+        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, false>(L, stream, grid, &lds, full64 != 0) : launch_d64<InF16, float, false>(L, stream, grid, &lds, full64 != 0);
     }
     *lds_out = (int)lds;
     return e;
