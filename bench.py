@@ -508,11 +508,13 @@ def main():
                       'sd15': 'table upload + zeroing, finalize_same / finalize_up32_mfma / finalize_up_kernel<16>'}[args.workload]
         fin_issue = dict(bound='issue', kernel=fin_kernel, clock=fin_clock, ms_per_launch=round(fin_ms, 4))
         if rec and fin_clock and rec.get('finalize_valu_busy_cycles_per_simd'):
-            cyc = rec['finalize_valu_busy_cycles_per_simd'] + 32.0 * rec.get('finalize_mfma_per_simd', 0)
+            n_mfma = rec.get('finalize_mfma_per_simd', 0)
+            cyc = max(rec['finalize_valu_busy_cycles_per_simd'] + 10.0 * n_mfma, 32.6 * n_mfma)
             fl = cyc / (fin_clock['mhz_median_under_load'] * 1e3)
             fin_issue.update(valu_busy_cycles_per_simd=rec['finalize_valu_busy_cycles_per_simd'],
-                             mfma_insts_per_simd=rec.get('finalize_mfma_per_simd'), mfma_cycles_each=32,
-                             model='VALU busy + matrix-pipe cycles (they add in this kernel: every VALU block consumes an MFMA result and feeds the next chain)',
+                             mfma_insts_per_simd=n_mfma, mfma_issue_block_cycles=10, mfma_pipe_cycles_each=32.6,
+                             model='max(VALU busy + 10 cycles of closed VALU port per MFMA, MFMA count x 32.6 cycles of matrix pipe) per SIMD '
+                                   '(tools/ubench_issue.hip); the class kernels only -- the timed launch also holds the table upload + zeroing kernel',
                              floor_ms=round(fl, 4), frac=round(fl / fin_ms, 4), source=prof_note)
         gpu_ms_per_gen = launches_per_gen * tap_ms + fin_ms
         extra = dict(

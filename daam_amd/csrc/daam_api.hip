@@ -902,7 +902,9 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         L.max_side = max_side;
         L.mfma_ops = (cls == 1 && keys[cls][0].tab == c->up32_tab) ? c->d_up32_ops : nullptr;
         if (cls == 0) {
-            L.n_chunks = std::max(1, std::min(n, env_chunks ? env_chunks : 4));
+            // 154 workgroups per chunk: 4 chunks for the 100 same-size keys of SDXL-1024, up to 16 (2464 workgroups, ~2.4 rounds)
+            // for the 1000 of SDXL-2048 -- a pure HBM stream wants every CU's queues full
+            L.n_chunks = std::max(1, std::min(n, env_chunks ? env_chunks : std::min(16, std::max(4, n / 32))));
         } else if (cls == 3) {
             L.n_chunks = std::max(1, std::min(n, 32));
         } else {

@@ -368,6 +368,81 @@ def test_context_reuse_between_engines(fake_engine):
     assert not E._PARKED and lib.names().count('daam_ctx_destroy') == 3
 
 
+def test_views_keep_their_buffers(fake_engine):
+    """The tensors ``all_heat_maps`` hands out are views of the live sums.  Like the reference's tensors they must survive
+    ``clear()`` and the end of the trace: an engine whose buffers were handed out starts the next generation on fresh ones
+    and is not parked for reuse."""
+    E, lib = fake_engine
+    E._PARKED.clear()
+    q, k = torch.zeros(2, 64, 16, dtype=torch.float16), torch.zeros(2, 77, 16, dtype=torch.float16)
+    a = E.HeatMapEngine(1, defer_steps=4, reuse_context=True)
+    a.tap_qk(0, q, k, 2, 0.35, 1)
+    views = [v for _, v in a.items()]
+    buf = a.acc[0]
+    assert a._views_out and views[0].data_ptr() == buf.data_ptr()
+    a.clear()                                                           # next generation: new buffers, the views keep the old ones
+    assert not a.acc and not a._views_out
+    a.tap_qk(0, q, k, 2, 0.35, 1)
+    assert a.acc[0].data_ptr() != buf.data_ptr() and lib.names().count('daam_layer_configure') == 2
+    list(a.items())
+    a.close()                                                           # views out: destroyed, not parked
+    assert lib.names()[-1] == 'daam_ctx_destroy' and not any(E._PARKED.values())
+    b = E.HeatMapEngine(1, defer_steps=4, reuse_context=True)           # never iterated: parked as before
+    b.tap_qk(0, q, k, 2, 0.35, 1)
+    b.close()
+    assert sum(len(v) for v in E._PARKED.values()) == 1
+    E.release_parked_contexts()
+
+
+def test_in_place_guard_and_stream_handover(fake_engine, monkeypatch):
+    """DAAM_CHECK_VERSIONS=1: the Python recorder remembers tensor._version and refuses to launch after an in-place write;
+    a flush from another stream than the one the generation was recorded on orders the two streams both ways."""
+    E, lib = fake_engine
+    monkeypatch.setenv('DAAM_CHECK_VERSIONS', '1')
+    eng = E.HeatMapEngine(1, defer_steps=4)
+    assert eng._fast is None                                            # the C++ recorder keeps no versions
+    q, k = torch.zeros(2, 64, 16, dtype=torch.float16), torch.zeros(2, 77, 16, dtype=torch.float16)
+    eng.tap_qk(0, q, k, 2, 0.35, 1)
+    eng.flush()
+    eng.tap_qk(0, q, k, 2, 0.35, 1)
+    q.add_(1)
+    with pytest.raises(RuntimeError, match='modified in place'):
+        eng.flush()
+    assert not eng.pending_taps
+    monkeypatch.delenv('DAAM_CHECK_VERSIONS')
+
+    class _S:
+        def __init__(self, h):
+            self.cuda_stream, self.waited = h, []
+
+        def wait_stream(self, other):
+            self.waited.append(other.cuda_stream)
+
+        def wait_event(self, ev):
+            pass
+
+        def record_event(self):
+            return object()
+    rec, cur = _S(11), _S(22)
+    eng2 = E.HeatMapEngine(1, defer_steps=4)
+    monkeypatch.setattr(E.HeatMapEngine, '_current_stream', lambda self: rec)
+    eng2.clear()
+    eng2.tap_qk(0, q, k, 2, 0.35, 1)                                    # first tap of the generation: recording stream = 11
+    monkeypatch.setattr(E.HeatMapEngine, '_current_stream', lambda self: cur)
+    eng2.flush()                                                        # read from stream 22
+    assert cur.waited == [11] and rec.waited == [22]
+    flush = [c for c in lib.calls if c[0] == 'daam_tap_flush'][-1]
+    assert flush[1][1] == 22                                            # the launch goes to the reading stream
+
+
+def test_bench_refuses_fewer_gpus_than_asked(monkeypatch):
+    """``python bench.py --gpus 8`` on a box with fewer devices must not print an n_gpus: 1 line."""
+    import bench
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)
+    with pytest.raises(SystemExit, match='only 1 GPU'):
+        bench._respawn_under_launcher(8)
+
+
 def test_defer_budget_defaults(monkeypatch):
     """$DAAM_DEFER_BYTES wins; otherwise 32 GiB capped at a quarter of the free device memory (at least 1 GiB)."""
     import sys
