@@ -256,9 +256,13 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
 
 // FULL64: every layer of the launch has head_dim == 64 (SDXL): the zero-padding selects of the head_dim < 64 case (8 VALU per
 // wave-step) are compiled out
+#ifndef DAAM_TAP_QDEPTH
+#define DAAM_TAP_QDEPTH 1          // steps the Q fetch runs ahead (2: a second register set, 3 waves per SIMD)
+#endif
 template <typename IN, typename ACC_T, bool FAST_EXP, bool FULL64>
-__global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
+__global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16 && DAAM_TAP_QDEPTH == 1) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
 {
+    constexpr int kQDepth = DAAM_TAP_QDEPTH;
     constexpr int KCH = (kTok * 8 + 255) / 256;               // 16-B K pieces per thread per step (3)
     constexpr int VEC = AccVec<ACC_T>::kPerVec;
     constexpr int PPR = kMfmaPixels / VEC;
@@ -358,54 +362,69 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     const int px0 = min(p0 + wave * 32 + j, lay.hw - 1), px1 = min(p0 + wave * 32 + 16 + j, lay.hw - 1);
     const bool qv0 = 8 * h < d, qv1 = 32 + 8 * h < d;         // this lane's piece of k-step 0 / 1 exists
     const int qo0 = qv0 ? 8 * h : 0, qo1 = qv1 ? 32 + 8 * h : 0;
-    const int64_t q_row0 = q_off + (int64_t)px0 * lay.q_sp;
-    const int64_t q_row1 = q_off + (int64_t)px1 * lay.q_sp;
+    // Addresses = wave-uniform base (the step's tensor pointer, made an SGPR pair by readfirstlane) + a 32-bit per-lane BYTE
+    // offset that never changes: the loads take the scalar-base form and the loop has no 64-bit address arithmetic (10
+    // v_lshl_add_u64 per wave-step before) and 4 address registers fewer.  tap_d64_supported() keeps every offset below 2^31.
+    const unsigned q_b0 = (unsigned)((q_off + (int64_t)px0 * lay.q_sp) * 2), q_b1 = (unsigned)((q_off + (int64_t)px1 * lay.q_sp) * 2);
+    const unsigned q_o0 = (unsigned)qo0 * 2, q_o1 = (unsigned)qo1 * 2;
+    auto uniform = [](const void* p) -> const char* {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    };
 
     float4v kreg[KCH];
-    half8 bq0[2], bq1[2];
     auto issue_k = [&](int s) {
-        const _Float16* kp = reinterpret_cast<const _Float16*>(sptr[2 * s + 1]) + k_off;
+        const char* kp = uniform(sptr[2 * s + 1]) + k_off * 2;
 #pragma unroll
-        for (int j2 = 0; j2 < KCH; ++j2) kreg[j2] = *as_global<float4v>(kp + k_src[j2]);
+        for (int j2 = 0; j2 < KCH; ++j2) kreg[j2] = *as_global<float4v>(kp + (unsigned)k_src[j2] * 2u);
     };
     auto commit_k = [&](int buf) {
 #pragma unroll
         for (int j2 = 0; j2 < KCH; ++j2)
             if (k_dst[j2] >= 0) *reinterpret_cast<float4v*>(kbuf + buf * kD64KBuf + k_dst[j2]) = kreg[j2];
     };
-    auto issue_q = [&](int s) {
-        const _Float16* qp = reinterpret_cast<const _Float16*>(sptr[2 * s]);
-        bq0[0] = *as_global<half8>(qp + q_row0 + qo0);
-        bq0[1] = *as_global<half8>(qp + q_row0 + qo1);
-        bq1[0] = *as_global<half8>(qp + q_row1 + qo0);
-        bq1[1] = *as_global<half8>(qp + q_row1 + qo1);
+    // Q of one step: this lane's two 16-byte pieces for each of its two pixel groups
+    struct QRegs { half8 g0[2], g1[2]; };
+    auto issue_q = [&](int s, QRegs& q) {
+        const char* qp = uniform(sptr[2 * s]);
+        q.g0[0] = *as_global<half8>(qp + (q_b0 + q_o0));
+        q.g0[1] = *as_global<half8>(qp + (q_b0 + q_o1));
+        q.g1[0] = *as_global<half8>(qp + (q_b1 + q_o0));
+        q.g1[1] = *as_global<half8>(qp + (q_b1 + q_o1));
     };
     const unsigned char* a_rd = kbuf + j * kD64Row + h * 16;  // + buf * kD64KBuf + mt * 16 rows + ks * 64
 
-    issue_k(0);
-    issue_q(0);
-    commit_k(0);
-    for (int s = 0; s < n_steps; ++s) {
+    // one denoising step: logits of step s from q (fetched kQDepth steps ago) and the K tile in LDS, then the fetches of later
+    // steps (K: step s + 1 into registers; Q: step s + kQDepth into the registers this step just freed), softmax + accumulate
+    // of the two pixel groups, K of step s + 1 into the other LDS buffer
+    auto step = [&](int s, QRegs& q) {
+#if !defined(DAAM_TAP_ABLATE) || DAAM_TAP_ABLATE != 1         // timing experiment 1: no per-step barrier (results are wrong)
         __syncthreads();
+#endif
         const unsigned char* kb = a_rd + (s & 1) * kD64KBuf;
         if (partial) {
             const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (!qv0) { bq0[0] = z; bq1[0] = z; }
-            if (!qv1) { bq0[1] = z; bq1[1] = z; }
+            if (!qv0) { q.g0[0] = z; q.g1[0] = z; }
+            if (!qv1) { q.g0[1] = z; q.g1[1] = z; }
         }
         floatx4 c0[5], c1[5];
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
             const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kD64Row);
             const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kD64Row + 64);
-            c0[mt] = IN::mfma(a0, bq0[0], floatx4{0, 0, 0, 0});
-            c1[mt] = IN::mfma(a0, bq1[0], floatx4{0, 0, 0, 0});
-            c0[mt] = IN::mfma(a1, bq0[1], c0[mt]);
-            c1[mt] = IN::mfma(a1, bq1[1], c1[mt]);
+            c0[mt] = IN::mfma(a0, q.g0[0], floatx4{0, 0, 0, 0});
+            c1[mt] = IN::mfma(a0, q.g1[0], floatx4{0, 0, 0, 0});
+            c0[mt] = IN::mfma(a1, q.g0[1], c0[mt]);
+            c1[mt] = IN::mfma(a1, q.g1[1], c1[mt]);
         }
-        const int nx = min(s + 1, n_steps - 1);               // branch-free: the last step re-fetches itself
-        issue_k(nx);
-        issue_q(nx);
+#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 2           // timing experiment 2: every step re-reads step 0 (cache-resident)
+        issue_k(0);
+        issue_q(0, q);
+#else
+        issue_k(min(s + 1, n_steps - 1));                     // branch-free: the last steps re-fetch the last one
+        issue_q(min(s + kQDepth, n_steps - 1), q);
+#endif
         if constexpr (IN::kBf16) {
             softmax20_accumulate_bf16<ACC_T>(c0, lay, h, run0);
             softmax20_accumulate_bf16<ACC_T>(c1, lay, h, run1);
@@ -414,6 +433,23 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
         }
         commit_k((s + 1) & 1);
+    };
+    QRegs qa;
+    issue_k(0);
+    issue_q(0, qa);
+    commit_k(0);
+    if constexpr (kQDepth == 1) {
+        for (int s = 0; s < n_steps; ++s) step(s, qa);
+    } else {
+        // Q two steps ahead in two register sets that alternate (static names: the loop is unrolled by two)
+        QRegs qb;
+        issue_q(min(1, n_steps - 1), qb);
+        int s = 0;
+        for (; s + 1 < n_steps; s += 2) {
+            step(s, qa);
+            step(s + 1, qb);
+        }
+        if (s < n_steps) step(s, qa);
     }
     __syncthreads();                                          // all K reads done before the staging tile reuses the space
 
