@@ -278,7 +278,7 @@ def _port_eager_on_device(th, kind, latent, denoise_steps, device, sample_steps=
                 maps_per_s=1.0 / (per_step * denoise_steps + t_fin))
 
 
-def integrated_overhead(device, steps=20, reps=7):
+def integrated_overhead(device, steps=50, reps=9):
     """Extraction overhead per denoising step INSIDE a model-shaped stack (metric (i), integrated harness):
     step time of a full-size synthetic SDXL-1024 cross-attention stack (70 attn2 modules, 60 hooked, fp16, CFG batch 2,
     tools/synthetic_unet.py) under ``daam_amd.trace`` -- incl. one compute_global_heat_map per generation -- minus its
@@ -305,22 +305,27 @@ def integrated_overhead(device, steps=20, reps=7):
     for _ in range(2):                                   # warm-up: code objects, allocator pools, parked trace context, clocks
         plain()
         traced()
-    # interleaved A / B generations and medians: the difference of two ~9 ms step times is what is measured, so clock
-    # ramps and allocator drift must hit both arms alike
+    # interleaved plain / traced generations; the overhead is the MEDIAN OF THE PAIRED DIFFERENCES: the difference of two
+    # ~8 ms step times is what is measured (the stack is bound by PyTorch's host-side launch rate), so clock ramps,
+    # allocator drift and host jitter must hit both members of a pair alike
     tp, tt = [], []
     for _ in range(reps):
         tp.append(once(plain))
         tt.append(once(traced))
+    diffs = sorted(t - p for p, t in zip(tp, tt))
+    overhead = diffs[len(diffs) // 2]
     tp.sort()
     tt.sort()
     t_plain, t_trace = tp[len(tp) // 2], tt[len(tt) // 2]
     del pipe
     torch.cuda.empty_cache()
     return dict(harness='synthetic SDXL-1024 cross-attention stack, 70 attn2 (60 hooked), fp16, CFG 2, '
-                        f'{steps} steps + compute_global_heat_map per generation; medians of {reps} interleaved plain / traced generations',
+                        f'{steps} steps + compute_global_heat_map per generation; {reps} interleaved plain / traced pairs, '
+                        'median of the paired differences',
                 plain_sdpa_ms_per_step=round(t_plain / steps * 1e3, 3), traced_ms_per_step=round(t_trace / steps * 1e3, 3),
-                overhead_ms_per_step=round((t_trace - t_plain) / steps * 1e3, 3),
-                spread_ms_per_step=round(max(tp[-1] - tp[0], tt[-1] - tt[0]) / steps * 1e3, 3))
+                overhead_ms_per_step=round(overhead / steps * 1e3, 3),
+                overhead_quartiles_ms_per_step=[round(diffs[len(diffs) // 4] / steps * 1e3, 3),
+                                                round(diffs[(3 * len(diffs)) // 4] / steps * 1e3, 3)])
 
 
 def _respawn_under_launcher(n):

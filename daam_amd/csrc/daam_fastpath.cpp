@@ -4,9 +4,13 @@
 // step: 3000 calls per 50-step SDXL generation (reference: the body of
 // UNetCrossAttentionHooker.__call__, daam/trace.py:285-294).  In deferred mode a call only has to
 // (1) check that the layer's Q / K look like they did when the layer's DaamQKDesc was built and
-// (2) remember two device pointers and keep the tensors alive until the launch.  Done in Python that
+// (2) remember two device pointers and keep their memory alive until the launch.  Done in Python that
 // is ~0.6 us per call, as much as the GPU needs for the tap itself; here it is one METH_FASTCALL
-// function that reads the at::Tensor fields directly.  Everything that is not the steady state
+// function that reads the at::Tensor fields directly.  What is kept is the c10::Storage, not the tensor:
+// the Python wrapper and the TensorImpl die where they would have died without the trace, only the
+// allocator block outlives the processor call.  After the launch the 6000 storages of an SDXL generation
+// go to a reaper thread (no GIL needed to return a block to the caching allocator), because freeing
+// them inline cost 4.8 ms of host time per generation -- twice the GPU time of the tap itself.  Everything that is not the steady state
 // (first call of a layer, shape / dtype change, non-contiguous input, window full) is handed back to
 // the Python engine through callbacks, so the validation logic and error messages live in one place
 // (daam_amd/engine.py).  No device work and no libdaam_hip calls happen here: the engine passes the
@@ -15,12 +19,97 @@
 #include <torch/csrc/autograd/python_variable.h>
 #include <ATen/core/Tensor.h>
 
+#include <c10/core/Storage.h>
+
+#include <pthread.h>
+
+#include <atomic>
 #include <climits>
-#include <exception>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
+
+// ---- reaper: returns recorded Q / K storages to the allocator off the interpreter's thread -------------------
+// One batch = the storages of one launch.  At most one batch waits while another is being freed: drop() blocks
+// (GIL released) until the previous batch is gone, so the memory that outlives a launch stays bounded by one
+// launch's worth.  A StorageImpl that owns a Python object (someone asked for tensor.untyped_storage()) takes
+// the GIL inside its own destructor; that is torch's business and merely slower.
+class Reaper {
+public:
+    using Batch = std::vector<c10::Storage>;
+
+    void submit(Batch&& batch) {
+        if (batch.empty()) return;
+        if (!usable()) { batch.clear(); return; }                 // synchronous: after shutdown(), in a forked child
+        std::unique_lock<std::mutex> lock(mu_);
+        if (!started_) {
+            started_ = true;
+            pid_thread_ = std::thread([this] { run(); });
+        }
+        idle_.wait(lock, [this] { return queue_.empty(); });
+        queue_.push_back(std::move(batch));
+        busy_ = true;
+        work_.notify_one();
+    }
+
+    void drain() {                                                // every submitted batch has been freed
+        if (!usable()) return;
+        std::unique_lock<std::mutex> lock(mu_);
+        idle_.wait(lock, [this] { return queue_.empty() && !busy_; });
+    }
+
+    void shutdown() {                                             // atexit: no thread may touch the allocator later
+        if (!usable()) return;
+        {
+            std::unique_lock<std::mutex> lock(mu_);
+            idle_.wait(lock, [this] { return queue_.empty() && !busy_; });
+            stop_ = true;
+            work_.notify_one();
+        }
+        if (started_ && pid_thread_.joinable()) pid_thread_.join();
+        off_.store(true);
+    }
+
+    void disable_after_fork() { off_.store(true); }               // the thread does not exist in the child
+    void set_sync(bool sync) { sync_.store(sync); }
+    bool usable() const { return !off_.load() && !sync_.load(); }
+
+private:
+    void run() {
+        std::unique_lock<std::mutex> lock(mu_);
+        for (;;) {
+            work_.wait(lock, [this] { return stop_ || !queue_.empty(); });
+            if (queue_.empty()) return;                           // stop_ with nothing queued
+            Batch batch = std::move(queue_.front());
+            queue_.pop_front();
+            idle_.notify_all();                                   // the next batch may queue up behind this one
+            lock.unlock();
+            batch.clear();                                        // ~StorageImpl -> allocator free, no GIL held
+            batch.shrink_to_fit();
+            lock.lock();
+            if (queue_.empty()) busy_ = false;
+            idle_.notify_all();
+        }
+    }
+
+    std::mutex mu_;
+    std::condition_variable work_, idle_;
+    std::deque<Batch> queue_;
+    std::thread pid_thread_;
+    bool started_ = false, stop_ = false, busy_ = false;
+    std::atomic<bool> off_{false}, sync_{false};
+};
+
+Reaper& reaper() {
+    static Reaper* r = new Reaper();                              // never destroyed: no static-destruction-order races
+    return *r;
+}
 
 struct LayerCache {
     bool valid = false;
@@ -44,7 +133,7 @@ struct Recorder {
     std::vector<uint64_t>* qp;
     std::vector<uint64_t>* kp;
     std::vector<uint64_t>* dp;
-    std::vector<at::Tensor>* keep;      // Q / K of the recorded taps stay alive until drop()
+    std::vector<c10::Storage>* keep;    // memory of the recorded Q / K stays allocated until drop()
     int window;                         // steps of one layer per launch
     int64_t budget;                     // bytes of recorded Q / K kept alive before a launch is forced
     int64_t held;                       // bytes of Q / K currently recorded
@@ -66,7 +155,7 @@ int Recorder_init(Recorder* self, PyObject* args, PyObject* kw) {
     self->qp = new std::vector<uint64_t>();
     self->kp = new std::vector<uint64_t>();
     self->dp = new std::vector<uint64_t>();
-    self->keep = new std::vector<at::Tensor>();
+    self->keep = new std::vector<c10::Storage>();
     self->window = 1;
     self->budget = INT64_MAX;
     self->held = 0;
@@ -117,8 +206,8 @@ inline void push(Recorder* self, int layer, const at::Tensor& q, const at::Tenso
     self->qp->push_back(reinterpret_cast<uint64_t>(q.data_ptr()));
     self->kp->push_back(reinterpret_cast<uint64_t>(k.data_ptr()));
     self->dp->push_back(desc);
-    self->keep->push_back(q);
-    self->keep->push_back(k);
+    self->keep->push_back(q.storage());
+    self->keep->push_back(k.storage());
     self->held += static_cast<int64_t>(q.nbytes()) + static_cast<int64_t>(k.nbytes());
     (*self->cnt)[layer] += 1;
 }
@@ -242,7 +331,16 @@ PyObject* Recorder_buffers(Recorder* self, PyObject*) {
 
 PyObject* Recorder_drop(Recorder* self, PyObject*) {                   // forget the recorded taps
     self->layers->clear(); self->qp->clear(); self->kp->clear(); self->dp->clear();
-    self->keep->clear();
+    if (self->keep->size() >= 64 && reaper().usable()) {
+        std::vector<c10::Storage> batch;
+        batch.reserve(self->keep->capacity());
+        batch.swap(*self->keep);
+        Py_BEGIN_ALLOW_THREADS                                  // may wait for the previous batch
+        reaper().submit(std::move(batch));
+        Py_END_ALLOW_THREADS
+    } else {
+        self->keep->clear();
+    }
     self->held = 0;
     std::fill(self->cnt->begin(), self->cnt->end(), 0);
     Py_RETURN_NONE;
@@ -302,7 +400,39 @@ PyMethodDef Recorder_methods[] = {
 
 PyTypeObject RecorderType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 
-PyModuleDef module_def = {PyModuleDef_HEAD_INIT, "_fastpath", "host-side recorder of deferred DAAM taps", -1, nullptr};
+PyObject* module_drain(PyObject*, PyObject*) {                         // every released storage is back in the allocator
+    Py_BEGIN_ALLOW_THREADS
+    reaper().drain();
+    Py_END_ALLOW_THREADS
+    Py_RETURN_NONE;
+}
+
+PyObject* module_shutdown(PyObject*, PyObject*) {                      // registered with atexit by daam_amd.engine
+    Py_BEGIN_ALLOW_THREADS
+    reaper().shutdown();
+    Py_END_ALLOW_THREADS
+    Py_RETURN_NONE;
+}
+
+PyObject* module_set_sync_release(PyObject*, PyObject* arg) {          // True: drop() frees inline (DAAM_SYNC_RELEASE=1)
+    const int on = PyObject_IsTrue(arg);
+    if (on < 0) return nullptr;
+    if (on) {
+        Py_BEGIN_ALLOW_THREADS
+        reaper().drain();
+        Py_END_ALLOW_THREADS
+    }
+    reaper().set_sync(on != 0);
+    Py_RETURN_NONE;
+}
+
+PyMethodDef module_methods[] = {
+    {"drain", module_drain, METH_NOARGS, "wait until the storages released by Recorder.drop() are back in the allocator"},
+    {"shutdown", module_shutdown, METH_NOARGS, "drain and stop the release thread; later drops free inline"},
+    {"set_sync_release", module_set_sync_release, METH_O, "free recorded storages inline instead of on the release thread"},
+    {nullptr, nullptr, 0, nullptr}};
+
+PyModuleDef module_def = {PyModuleDef_HEAD_INIT, "_fastpath", "host-side recorder of deferred DAAM taps", -1, module_methods};
 
 }  // namespace
 
@@ -317,6 +447,7 @@ PyMODINIT_FUNC PyInit__fastpath(void) {
     RecorderType.tp_dealloc = reinterpret_cast<destructor>(Recorder_dealloc);
     RecorderType.tp_methods = Recorder_methods;
     if (PyType_Ready(&RecorderType) < 0) return nullptr;
+    pthread_atfork(nullptr, nullptr, [] { reaper().disable_after_fork(); });
     PyObject* m = PyModule_Create(&module_def);
     if (!m) return nullptr;
     Py_INCREF(&RecorderType);

@@ -34,6 +34,35 @@ _PARKED: Dict[tuple, list] = {}
 _PARK_LIMIT = 2
 
 
+_FASTPATH_READY = False
+
+
+def _load_fastpath():
+    """The C++ recorder, or None when the extension is not built.  Its release thread (the storages of the recorded
+    Q / K go back to the caching allocator off the interpreter's thread) is drained and stopped at interpreter exit,
+    while torch is still intact; ``DAAM_SYNC_RELEASE=1`` frees inline instead."""
+    global _FASTPATH_READY
+    try:
+        from . import _fastpath
+    except ImportError:
+        return None
+    if not _FASTPATH_READY:
+        import atexit
+        atexit.register(_fastpath.shutdown)
+        if os.environ.get('DAAM_SYNC_RELEASE'):
+            _fastpath.set_sync_release(True)
+        _FASTPATH_READY = True
+    return _fastpath
+
+
+def drain_released() -> None:
+    """Block until every Q / K block released by a finished launch is back in the caching allocator (they are freed on
+    a helper thread).  Only memory accounting needs this (``torch.cuda.memory_allocated`` right after a trace)."""
+    fp = _load_fastpath()
+    if fp is not None:
+        fp.drain()
+
+
 def release_parked_contexts() -> None:
     """Destroy every parked context now (frees their sum buffers too).  Not called at interpreter exit on purpose:
     process teardown reclaims them, and no HIP call has to run while the runtime is shutting down."""
@@ -89,10 +118,7 @@ class HeatMapEngine:
         # pointers -- all arithmetic is in libdaam_hip either way.
         self._fast = None
         if self.defer_steps and not os.environ.get('DAAM_NO_FASTPATH') and not self._check_versions:
-            try:
-                from . import _fastpath
-            except ImportError:
-                _fastpath = None
+            _fastpath = _load_fastpath()
             if _fastpath is not None:
                 # the recorder calls back into this engine through a weak reference: engine -> recorder is the
                 # only strong edge, so dropping the trace frees the context and the running sums at once

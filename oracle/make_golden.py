@@ -141,6 +141,10 @@ def run_case(name, spec, daam):
         out['keys'] = keys
         out['key_sum'] = np.asarray([float(v.double().sum()) for _, v in items])
         out['key_sumsq'] = np.asarray([float((v.double() ** 2).sum()) for _, v in items])
+        # every (key, token) plane: its sum and a position-weighted sum (a transposed or shifted plane changes the second)
+        out['plane_sum'] = np.stack([v.double().sum((1, 2)).numpy() for _, v in items])
+        out['plane_wsum'] = np.stack([(v.double() * torch.arange(1, v.shape[1] * v.shape[2] + 1, dtype=torch.float64)
+                                       .view(1, v.shape[1], v.shape[2])).sum((1, 2)).numpy() for _, v in items])
         out['raw_dtype'] = np.asarray(str(items[0][1].dtype))
         # one sampled raw map per distinct resolution (first + last key of that factor)
         sample_ids = []

@@ -305,6 +305,13 @@ def test_trace_api_matches_reference_golden(golden_case, tap, defer, tmp_path):
         assert str(items[0][1].dtype) == str(z['raw_dtype'])
         sums = np.asarray([float(v.double().sum()) for _, v in items])
         np.testing.assert_allclose(sums, z['key_sum'], rtol={'float32': 1e-5, 'float16': 2e-4, 'bfloat16': 2e-3}[meta['dtype']])
+        # every (key, token) plane of the reference's run, by two checksums (sum and position-weighted sum)
+        rt = {'float32': 1e-5, 'float16': 1e-3, 'bfloat16': 8e-3}[meta['dtype']]
+        ps = np.stack([v.double().sum((1, 2)).cpu().numpy() for _, v in items])
+        pw = np.stack([(v.double() * torch.arange(1, v.shape[1] * v.shape[2] + 1, dtype=torch.float64, device=v.device)
+                        .view(1, v.shape[1], v.shape[2])).sum((1, 2)).cpu().numpy() for _, v in items])
+        np.testing.assert_allclose(ps, z['plane_sum'], rtol=rt, atol=rt)
+        np.testing.assert_allclose(pw, z['plane_wsum'], rtol=rt, atol=rt * 1e3)
         for sid in z['raw_sample_ids']:
             got = items[int(sid)][1][SAMPLE_TOKENS].float().cpu().numpy()
             want = z[f'raw_{int(sid)}']

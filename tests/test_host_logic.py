@@ -291,6 +291,44 @@ def test_cxx_recorder_steady_state(fake_engine):
     eng.close()
 
 
+def test_cxx_recorder_releases_storages_on_its_thread(fake_engine):
+    """The recorder keeps the STORAGE of a recorded Q / K (the tensor object dies with the processor call, as it would
+    without a trace) and hands the storages of a launch to its release thread; ``drain_released`` waits for it."""
+    import weakref
+    E, lib = fake_engine
+    from daam_amd import _fastpath
+    eng = E.HeatMapEngine(1, defer_steps=64)
+    k = torch.zeros(2, 77, 16, dtype=torch.float16)
+    watched = []
+    for step in range(40):                                   # > 64 storages: the batch goes to the thread
+        q = torch.zeros(2, 64, 16, dtype=torch.float16)
+        if step % 8 == 0:
+            watched.append((weakref.ref(q), q.untyped_storage()))     # a storage with a Python object: freed under the GIL
+        eng.tap_qk(0, q, k, 2, 0.35, 1)
+        del q
+    assert all(ref() is None for ref, _ in watched)          # tensors are gone, their memory is held
+    held = [torch._C._storage_Use_Count(st._cdata) for _, st in watched]
+    eng.flush()
+    E.drain_released()
+    assert [torch._C._storage_Use_Count(st._cdata) for _, st in watched] == [c - 1 for c in held]
+    assert eng.pending_taps == 0 and eng._fast.held_bytes() == 0
+    # inline release gives the same result
+    _fastpath.set_sync_release(True)
+    try:
+        q = torch.zeros(2, 64, 16, dtype=torch.float16)
+        st = q.untyped_storage()
+        for _ in range(70):
+            eng.tap_qk(0, q, k, 2, 0.35, 1)
+            if eng._fast.pending(0) == 64:
+                break
+        before = torch._C._storage_Use_Count(st._cdata)
+        eng.flush()
+        assert torch._C._storage_Use_Count(st._cdata) == before - 64
+    finally:
+        _fastpath.set_sync_release(False)
+    eng.close()
+
+
 @pytest.mark.parametrize('recorder', ['c++', 'python'])
 def test_defer_byte_budget(fake_engine, monkeypatch, recorder):
     """The recorded Q / K are kept alive until their launch: a byte budget forces the launch early."""

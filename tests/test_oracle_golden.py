@@ -29,6 +29,13 @@ def test_oracle_matches_reference(golden_case):
     sums = np.asarray([float(v.astype(np.float64).sum()) for _, v in raw])
     np.testing.assert_allclose(sums, z['key_sum'], rtol={'float32': 1e-5, 'float16': 1e-4, 'bfloat16': 2e-3}[meta['dtype']])
     items = list(raw)
+    # EVERY (key, token) plane, by two checksums (plain and position-weighted: a transposed / shifted plane changes the second)
+    rt = {'float32': 1e-5, 'float16': 1e-3, 'bfloat16': 8e-3}[meta['dtype']]
+    ps = np.stack([v.astype(np.float64).sum((1, 2)) for _, v in items])
+    pw = np.stack([(v.astype(np.float64) * np.arange(1, v.shape[1] * v.shape[2] + 1, dtype=np.float64).reshape(1, v.shape[1], v.shape[2])).sum((1, 2))
+                   for _, v in items])
+    np.testing.assert_allclose(ps, z['plane_sum'], rtol=rt, atol=rt)
+    np.testing.assert_allclose(pw, z['plane_wsum'], rtol=rt, atol=rt * 1e3)
     for sid in z['raw_sample_ids']:
         got = items[int(sid)][1][SAMPLE_TOKENS].astype(np.float32)
         want = z[f'raw_{int(sid)}']

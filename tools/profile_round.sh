@@ -16,6 +16,12 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $PM > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $PM > $O/pmc_write.log 2>&1
 cd $R
+# gpurun_out/ does not travel TO the box: start from the committed per-round files so that the per-workload entries of one
+# build accumulate (summarize_profiles.py starts a new file when the kernel sources changed)
+mkdir -p gpurun_out/profiles_$TAG
+for f in ${TAG}_counters.json hbm_traffic.json; do
+    [ -f gpurun_out/profiles_$TAG/$f ] || { [ -f profiles/$f ] && cp profiles/$f gpurun_out/profiles_$TAG/$f; }
+done
 python tools/summarize_profiles.py --tag ${TAG}_$WL --stats $O/stats --pmc $O/pmc_sq $O/pmc_mfma $O/pmc_fetch $O/pmc_write --key $KEY --out gpurun_out/profiles_$TAG
 for f in $O/*.log; do tail -n 2 $f | cut -c1-200; done
 rm -rf $O/stats $O/pmc_sq $O/pmc_mfma $O/pmc_fetch $O/pmc_write      # raw traces are > 64 MiB: only the summaries travel back

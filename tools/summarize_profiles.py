@@ -26,7 +26,7 @@ def find(d, suffix):
 def short(name):
     if 'daam' not in name:
         return None
-    for k in ('tap_d64_kernel', 'tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'finalize_up32_same_kernel', 'finalize_up32_mfma_kernel',
+    for k in ('tap_d64_kernel', 'tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_down2_kernel',
               'finalize_up_kernel', 'finalize_same_kernel', 'finalize_kernel', 'normalize_kernel', 'word_'):
         if k in name:
             return k
@@ -115,7 +115,7 @@ def main():
                 w['tap_mfma_per_simd'] = round(sum(upper_median(pmc[k]['SQ_INSTS_MFMA']) for k in tap_names) / 1024, 1)
             if all('SQ_VALU_MFMA_BUSY_CYCLES' in pmc[k] for k in tap_names):
                 w['tap_mfma_busy_cycles_per_simd'] = round(sum(upper_median(pmc[k]['SQ_VALU_MFMA_BUSY_CYCLES']) for k in tap_names) / 1024, 1)
-        fin_names = [k for k in ('finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_same_kernel', 'finalize_up_kernel',
+        fin_names = [k for k in ('finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_same_kernel', 'finalize_down2_kernel', 'finalize_up_kernel',
                                  'finalize_kernel') if k in pmc and 'SQ_ACTIVE_INST_VALU' in pmc[k]]
         if fin_names:
             w['finalize_valu_busy_cycles_per_simd'] = round(sum(upper_median(pmc[k]['SQ_ACTIVE_INST_VALU']) for k in fin_names) * 4 / 1024, 1)
