@@ -37,6 +37,8 @@ bool finalize_down2_supported(int side, int out_side);
 hipError_t launch_finalize_down2(const FinLaunch&, int, hipStream_t, int*);
 hipError_t launch_normalize(float*, int, int, hipStream_t);
 hipError_t launch_mask_overlap(const float*, int, int, const float*, int, int, int, float*, hipStream_t);
+bool attend_d64_supported(int in_dtype, int head_dim, int tokens, const int64_t* strides, int n_strides, const void* const* ptrs, int n_ptrs);
+hipError_t launch_attend_d64(const AttendLaunch&, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
 hipError_t launch_clock_monitor(unsigned long long* samples, int n_samples, int period_us, hipStream_t);
 constexpr int kClockMaxSamples = 4096;
 hipError_t launch_word(const float*, int, const int32_t*, int, float*, float*, int, int, int, float, float*,
@@ -572,6 +574,61 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     if (e != hipSuccess) return fail((int)e, "tap launch: %s", hipGetErrorString(e));
     c->layers[layer].dirty = true;
     c->layers[layer].zero_pending = false;
+    return 0;
+}
+
+int daam_attend_supported(const DaamAttendDesc* d, const void* q, const void* k, const void* v, const void* out)
+{
+    if (!d || !q || !k || !v || !out) return 0;
+    const int64_t strides[] = {d->qk.q_stride_b, d->qk.q_stride_h, d->qk.q_stride_p, d->qk.k_stride_b, d->qk.k_stride_h,
+                               d->qk.k_stride_t, d->v_stride_b, d->v_stride_h, d->v_stride_t, d->o_stride_b, d->o_stride_h,
+                               d->o_stride_p};
+    const void* ptrs[] = {q, k, v, out};
+    if (d->qk.batch <= 0 || d->qk.heads <= 0 || d->qk.hw <= 0) return 0;
+    return attend_d64_supported(d->qk.in_dtype, d->qk.head_dim, d->qk.tokens, strides, 12, ptrs, 4) ? 1 : 0;
+}
+
+int daam_attend(DaamCtx* c, int layer, const void* q, const void* k, const void* v, void* out, const DaamAttendDesc* d,
+                int tap, void* stream)
+{
+    if (!c || !d || !q || !k || !v || !out) return fail(DAAM_E_INVALID, "NULL argument");
+    if (!daam_attend_supported(d, q, k, v, out))
+        return fail(DAAM_E_UNSUPPORTED, "daam_attend: fp16, head_dim 64, 77 tokens, strides %% 8 == 0, 16-byte aligned pointers only");
+    if (d->qk.tokens != c->tokens) return fail(DAAM_E_INVALID, "tokens %d != context size %d", d->qk.tokens, c->tokens);
+    if (tap) {
+        int rc = check_qk(c, layer, q, k, &d->qk);
+        if (rc) return rc;
+        if (!c->pending.empty()) return fail(DAAM_E_STATE, "fused tap with deferred taps pending: flush first");
+    }
+    DeviceGuard on_device(c);
+    AttendLaunch L;
+    memset(&L, 0, sizeof L);
+    L.q = q; L.k = k; L.v = v; L.out = out;
+    L.batch = d->qk.batch; L.heads = d->qk.heads; L.hw = d->qk.hw;
+    L.tiles_per_head = (d->qk.hw + tap_mfma_tile_pixels() - 1) / tap_mfma_tile_pixels();
+    L.total_wgs = L.batch * L.heads * L.tiles_per_head;
+    L.wgs_per_xcd = (L.total_wgs + 7) / 8;
+    L.bh_first = (d->qk.batch * d->qk.heads) / 2;
+    L.round_logits = d->qk.round_logits;
+    L.scale = d->qk.scale;
+    L.q_sb = d->qk.q_stride_b; L.q_sh = d->qk.q_stride_h; L.q_sp = d->qk.q_stride_p;
+    L.k_sb = d->qk.k_stride_b; L.k_sh = d->qk.k_stride_h; L.k_st = d->qk.k_stride_t;
+    L.v_sb = d->v_stride_b; L.v_sh = d->v_stride_h; L.v_st = d->v_stride_t;
+    L.o_sb = d->o_stride_b; L.o_sh = d->o_stride_h; L.o_sp = d->o_stride_p;
+    if (tap) {
+        L.acc = c->layers[layer].acc;
+        L.fresh = c->layers[layer].dirty ? 0 : 1;
+    }
+    int grid = 0, lds = 0;
+    hipError_t e = launch_attend_d64(L, c->acc_dtype, c->fast_exp && d->qk.round_logits, (hipStream_t)stream, &grid, &lds);
+    if (e != hipSuccess) return fail((int)e, "attend launch: %s", hipGetErrorString(e));
+    if (tap) {
+        c->last_grid[0] = grid;
+        c->last_block[0] = 256;
+        c->last_lds[0] = lds;
+        c->layers[layer].dirty = true;
+        c->layers[layer].zero_pending = false;
+    }
     return 0;
 }
 

@@ -1,0 +1,292 @@
+// Cross-attention of one UNet layer call with the heat-map tap fused in: out = softmax(scale Q K^T) V for every
+// (batch, head), and -- for the kept (conditional) heads, when the launch carries the layer's running sums -- sums += P
+// from the SAME fp16 probabilities, in one kernel.  fp16 pipeline, head_dim 64, 77 keys (every SDXL / SD-2.x
+// cross-attention), gfx950, v_mfma_f32_16x16x32_f16.
+//
+// Replaces, inside the reference's attention processor, get_attention_scores (daam/trace.py:276; diffusers 0.21.2:
+// baddbmm -> fp16 logits -> f32 softmax -> fp16 probabilities), the per-head update loop (daam/trace.py:289-294 with
+// _unravel_attn :219-244 and heatmap.py:153-156) and torch.bmm(probs, value) + batch_to_head_dim (daam/trace.py:296-297),
+// with the reference's rounding points:
+//   logits = fp16(f32(q.k) * scale) -> f32 softmax -> p = fp16(.) -> out = fp16(sum_t f32(p_t * v_t)),  sums += p.
+//
+// Tiling (daam_tap16.h): workgroup = 256 threads = 4 waves = 128 pixels of one (batch, head); a wave owns 32 pixels as two
+// groups of 16.  S^T = K Q^T puts the 77 probabilities of a pixel into four lanes x 20 slots; exactly that register layout
+// is the B operand (P^T) of the second product O^T = V^T P^T when the key slots of V^T are stored in the same permuted
+// order (v_slot_byte), so the probabilities never leave the registers between the two MFMA stages.  O^T tile: lane holds
+// pixel l&15 and 4 consecutive head_dim elements -> one 8-byte store into out[batch, pixel, head*64 + ...], the
+// [batch, hw, heads*64] layout the output projection consumes (no transpose / reshape copy afterwards).
+// LDS: K [80 rows][160 B] (A operand of S^T), V^T [64 rows][96 key slots, 208 B] (A operand of O^T), and for the tap a
+// [77][128] fp16 tile of probabilities that turns the lanes' scattered 2-byte values into 16-byte row pieces of the sums.
+#include "daam_tap16.h"
+
+namespace daam {
+
+constexpr int kVRow = 208;                         // bytes per V^T row: 96 key slots x 2 B + 16 pad (13 x 16 B: conflict-free b128 rows)
+constexpr int kVBuf = 64 * kVRow;                  // 13312
+constexpr int kStageOff = kD64KBuf + kVBuf;        // probabilities tile of the tap
+constexpr int kAttendLds = kStageOff + kTok * kMfmaPixels * 2;     // 45824
+
+// byte offset of key `t` inside a V^T row: k-block kb = t / 32 of the second product, lane quarter x / 4 supplies slots
+// 8*(x/4) + e, e < 4 from S^T row tile 2 kb (tokens 32 kb + ..), e >= 4 from row tile 2 kb + 1 (tokens 32 kb + 16 + ..)
+__device__ __forceinline__ constexpr int v_slot_byte(int t) {
+    const int kb = t >> 5, u = (t >> 4) & 1, x = t & 15;
+    return (kb * 32 + (x >> 2) * 8 + u * 4 + (x & 3)) * 2;
+}
+
+// fp16 probabilities of the lane's 20 token slots (slot pairs), the arithmetic of softmax20_accumulate (daam_tap_d64.hip)
+// up to the point where that one adds them to the running sums; tests/test_gpu_attend.py holds the two to bit-identical sums
+template <bool FAST_EXP>
+__device__ __forceinline__ void softmax20_probs(const floatx4 (&c)[5], float scale, int round_logits, int h,
+                                                half2v (&ph)[kSlots16 / 2])
+{
+    if constexpr (FAST_EXP) {
+        const bool pow2 = (__float_as_uint(scale) & 0x007fffffu) == 0;          // wave-uniform
+        half2v xh[kSlots16 / 2];
+        if (pow2) {
+            // compiler-visible conversions: first VALU read of the MFMA results (MFMA -> VALU wait states)
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                xh[2 * mt] = __builtin_convertvector(float2v{c[mt][0], c[mt][1]}, half2v);
+                xh[2 * mt + 1] = __builtin_convertvector(float2v{c[mt][2], c[mt][3]}, half2v);
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                xh[2 * mt] = cvt_pk_rne(float2v{c[mt][0], c[mt][1]} * scale);
+                xh[2 * mt + 1] = cvt_pk_rne(float2v{c[mt][2], c[mt][3]} * scale);
+            }
+        }
+        if (h == 3) {                                                   // tokens 77, 78, 79
+            const _Float16 ninf = -(_Float16)__builtin_inff();
+            xh[8][1] = ninf;
+            xh[9] = half2v{ninf, ninf};
+        }
+        const float L = 1.44269502162933349609375f * (pow2 ? scale : 1.0f);
+        float2v ev[kSlots16 / 2];
+        auto exps = [&](float nmL) -> float {
+            float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < kSlots16 / 2; i += 2) {
+                ev[i] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][0], L, nmL)),
+                                __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][1], L, nmL))};
+                ev[i + 1] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][0], L, nmL)),
+                                    __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][1], L, nmL))};
+                sa += ev[i];
+                sb += ev[i + 1];
+            }
+            sa += sb;
+            return quad_sum(sa[0] + sa[1]);
+        };
+        float tot = exps(-quad_bcast0((float)xh[0][0]) * L);
+        if (__builtin_expect(!(tot <= 0x1p100f), 0)) {                   // large, inf or NaN: redo with the row maximum
+            half2v ma = xh[0], mb = xh[1];
+#pragma unroll
+            for (int i = 2; i < kSlots16 / 2; i += 2) {
+                ma = pk_max(ma, xh[i]);
+                mb = pk_max(mb, xh[i + 1]);
+            }
+            ma = pk_max(ma, mb);
+            tot = exps(-quad_max(fmaxf((float)ma[0], (float)ma[1])) * L);
+        }
+        const float inv = __builtin_amdgcn_rcpf(tot);
+#pragma unroll
+        for (int i = 0; i < kSlots16 / 2; ++i) ph[i] = cvt_pk_rne(ev[i] * inv);   // probs.to(dtype)
+    } else {
+        float x[kSlots16];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = c[mt][r] * scale;                        // alpha in f32, then the baddbmm output rounding
+                x[4 * mt + r] = round_logits ? (float)(_Float16)v : v;
+            }
+        if (h == 3) { x[17] = kMasked; x[18] = kMasked; x[19] = kMasked; }
+        float m0 = x[0], m1 = x[1], m2 = x[2], m3 = x[3];
+#pragma unroll
+        for (int i = 4; i < kSlots16; i += 4) {
+            m0 = fmaxf(m0, x[i]); m1 = fmaxf(m1, x[i + 1]); m2 = fmaxf(m2, x[i + 2]); m3 = fmaxf(m3, x[i + 3]);
+        }
+        const float m = quad_max(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kSlots16; i += 4) {
+            x[i] = exp_nonpos(x[i] - m);         s0 += x[i];
+            x[i + 1] = exp_nonpos(x[i + 1] - m); s1 += x[i + 1];
+            x[i + 2] = exp_nonpos(x[i + 2] - m); s2 += x[i + 2];
+            x[i + 3] = exp_nonpos(x[i + 3] - m); s3 += x[i + 3];
+        }
+        const float inv = 1.0f / quad_sum((s0 + s1) + (s2 + s3));
+#pragma unroll
+        for (int i = 0; i < kSlots16; ++i) ph[i >> 1][i & 1] = (_Float16)(x[i] * inv);   // probs.to(dtype)
+    }
+}
+
+template <typename ACC_T, bool FAST_EXP>
+__global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L)
+{
+    constexpr int KCH = (kTok * 8 + 255) / 256;               // 16-byte K (and V) pieces per thread (3)
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* kbuf = smem;
+    unsigned char* vbuf = smem + kD64KBuf;
+    _Float16* stage = reinterpret_cast<_Float16*>(smem + kStageOff);
+
+    const int wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
+    if (wg < 0) return;
+    const int tid = threadIdx.x;
+    const int bh = wg / L.tiles_per_head;
+    const int p0 = (wg - bh * L.tiles_per_head) * kMfmaPixels;
+    const int b = bh / L.heads, hd = bh - b * L.heads;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, h = lane >> 4;
+
+    // ---- global fetches first (K, V pieces; this lane's Q pieces), LDS zero-fill underneath ------------------------
+    const char* kp = reinterpret_cast<const char*>(L.k) + (b * L.k_sb + hd * L.k_sh) * 2;
+    const char* vp = reinterpret_cast<const char*>(L.v) + (b * L.v_sb + hd * L.v_sh) * 2;
+    const char* qp = reinterpret_cast<const char*>(L.q) + (b * L.q_sb + hd * L.q_sh) * 2;
+    float4v kreg[KCH], vreg[KCH];
+#pragma unroll
+    for (int j2 = 0; j2 < KCH; ++j2) {
+        const int c = tid + 256 * j2;
+        const int t = min(c >> 3, kTok - 1), ch = c & 7;
+        kreg[j2] = *as_global<float4v>(kp + ((int64_t)t * L.k_st + ch * 8) * 2);
+        vreg[j2] = *as_global<float4v>(vp + ((int64_t)t * L.v_st + ch * 8) * 2);
+    }
+    const int px[2] = {p0 + wave * 32 + j, p0 + wave * 32 + 16 + j};
+    half8 qreg[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const char* row = qp + (int64_t)min(px[g], L.hw - 1) * L.q_sp * 2;
+        qreg[g][0] = *as_global<half8>(row + (8 * h) * 2);
+        qreg[g][1] = *as_global<half8>(row + (32 + 8 * h) * 2);
+    }
+    for (int i = tid; i < 3 * (kD64Row / 16); i += 256)       // K rows 77..79 take part in the MFMAs: finite
+        *reinterpret_cast<float4v*>(kbuf + kTok * kD64Row + i * 16) = float4v{0, 0, 0, 0};
+    for (int i = tid; i < kVBuf / 16; i += 256)               // key slots 77..95 of V^T meet p = 0: must not be NaN / inf
+        *reinterpret_cast<float4v*>(vbuf + i * 16) = float4v{0, 0, 0, 0};
+    __syncthreads();
+#pragma unroll
+    for (int j2 = 0; j2 < KCH; ++j2) {
+        const int c = tid + 256 * j2;
+        const int t = c >> 3, ch = c & 7;
+        if (t < kTok) {
+            *reinterpret_cast<float4v*>(kbuf + t * kD64Row + ch * 16) = kreg[j2];
+            const half8 vv = __builtin_bit_cast(half8, vreg[j2]);
+            unsigned char* col = vbuf + v_slot_byte(t) + (8 * ch) * kVRow;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<_Float16*>(col + i * kVRow) = vv[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T ----------------------------------------------------------------------------------------------
+    const unsigned char* a_rd = kbuf + j * kD64Row + h * 16;
+    floatx4 c0[5], c1[5];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) {
+        const half8 a0 = *reinterpret_cast<const half8*>(a_rd + mt * 16 * kD64Row);
+        const half8 a1 = *reinterpret_cast<const half8*>(a_rd + mt * 16 * kD64Row + 64);
+        c0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, qreg[0][0], floatx4{0, 0, 0, 0}, 0, 0, 0);
+        c1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, qreg[1][0], floatx4{0, 0, 0, 0}, 0, 0, 0);
+        c0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, qreg[0][1], c0[mt], 0, 0, 0);
+        c1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, qreg[1][1], c1[mt], 0, 0, 0);
+    }
+    half2v ph[2][kSlots16 / 2];
+    softmax20_probs<FAST_EXP>(c0, L.scale, L.round_logits, h, ph[0]);
+    softmax20_probs<FAST_EXP>(c1, L.scale, L.round_logits, h, ph[1]);
+
+    // ---- tap: probabilities of the kept heads -> LDS tile [token][pixel] ------------------------------------------
+    const bool tap = L.acc != nullptr && bh >= L.bh_first;     // workgroup-uniform
+    if (tap) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < kSlots16; ++i) {
+                const int t = slot16_token(i, h);
+                if (t < kTok) stage[t * kMfmaPixels + wave * 32 + g * 16 + j] = ph[g][i >> 1][i & 1];
+            }
+    }
+
+    // ---- O^T = V^T P^T, out[batch, pixel, head*64 + d] ------------------------------------------------------------
+    const unsigned char* v_rd = vbuf + j * kVRow + h * 16;
+    _Float16* out = reinterpret_cast<_Float16*>(L.out) + b * L.o_sb + hd * L.o_sh;
+    const half2v z2 = {0, 0};
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+        half8 pb[3];
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) {
+            const half2v e0 = ph[g][4 * kb], e1 = ph[g][4 * kb + 1];
+            const half2v e2 = kb < 2 ? ph[g][(4 * kb + 2) % 10] : z2, e3 = kb < 2 ? ph[g][(4 * kb + 3) % 10] : z2;
+            pb[kb] = half8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            floatx4 o = {0, 0, 0, 0};
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) {
+                const half8 a = *reinterpret_cast<const half8*>(v_rd + mt * 16 * kVRow + kb * 64);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[kb], o, 0, 0, 0);
+            }
+            const half2v lo = __builtin_convertvector(float2v{o[0], o[1]}, half2v);
+            const half2v hi = __builtin_convertvector(float2v{o[2], o[3]}, half2v);
+            if (px[g] < L.hw)
+                *as_global_rw<half4v>(out + (int64_t)px[g] * L.o_sp + 16 * mt + 4 * h) = half4v{lo[0], lo[1], hi[0], hi[1]};
+        }
+    }
+
+    // ---- tap: sums[kept head][token][pixel] += p, 16-byte row pieces -----------------------------------------------
+    if (tap) {
+        __syncthreads();
+        ACC_T* acc = reinterpret_cast<ACC_T*>(L.acc) + (size_t)(bh - L.bh_first) * kTok * L.hw;
+        for (int piece = tid; piece < kTok * (kMfmaPixels / 8); piece += 256) {
+            const int row = piece >> 4, col = (piece & 15) * 8;
+            if (p0 + col >= L.hw) continue;
+            const half8 pv = *reinterpret_cast<const half8*>(stage + row * kMfmaPixels + col);
+            ACC_T* dst = acc + (size_t)row * L.hw + p0 + col;
+            if constexpr (sizeof(ACC_T) == 2) {
+                half8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (!L.fresh) a = *as_global<half8>(dst);
+                a += pv;                                                 // heatmap.py:156 in fp16 (v_pk_add_f16)
+                *as_global_rw<half8>(dst) = a;
+            } else {
+                float4v a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+                if (!L.fresh) { a0 = *as_global<float4v>(dst); a1 = *as_global<float4v>(dst + 4); }
+                a0 += float4v{(float)pv[0], (float)pv[1], (float)pv[2], (float)pv[3]};
+                a1 += float4v{(float)pv[4], (float)pv[5], (float)pv[6], (float)pv[7]};
+                *as_global_rw<float4v>(dst) = a0;
+                *as_global_rw<float4v>(dst + 4) = a1;
+            }
+        }
+    }
+}
+
+bool attend_d64_supported(int in_dtype, int head_dim, int tokens, const int64_t* strides, int n_strides, const void* const* ptrs,
+                          int n_ptrs)
+{
+    if (in_dtype != 0 || head_dim != 64 || tokens != kTok) return false;
+    for (int i = 0; i < n_strides; ++i)
+        if (strides[i] % 8 != 0 || strides[i] < 0 || strides[i] >= ((int64_t)1 << 40)) return false;
+    uintptr_t bits = 0;
+    for (int i = 0; i < n_ptrs; ++i) bits |= reinterpret_cast<uintptr_t>(ptrs[i]);
+    return (bits & 15) == 0;
+}
+
+hipError_t launch_attend_d64(const AttendLaunch& L, int acc_dtype, int fast_exp, hipStream_t stream, int* grid_out, int* lds_out)
+{
+    const int grid = L.wgs_per_xcd * 8;
+    *grid_out = grid;
+    *lds_out = kAttendLds;
+    if (acc_dtype == 0) {
+        if (fast_exp) hipLaunchKernelGGL((attend_d64_kernel<_Float16, true>), dim3(grid), dim3(256), kAttendLds, stream, L);
+        else hipLaunchKernelGGL((attend_d64_kernel<_Float16, false>), dim3(grid), dim3(256), kAttendLds, stream, L);
+    } else if (acc_dtype == 1) {
+        if (fast_exp) hipLaunchKernelGGL((attend_d64_kernel<float, true>), dim3(grid), dim3(256), kAttendLds, stream, L);
+        else hipLaunchKernelGGL((attend_d64_kernel<float, false>), dim3(grid), dim3(256), kAttendLds, stream, L);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace daam

@@ -19,44 +19,13 @@
 // l&15 and tokens 16*mt + 4*(l>>4) + r (mt = 0..4, r = 0..3) = 20 slots.
 // K of a step sits in LDS as [80 rows][128 B + 32 B pad] (pad 32: conflict-free ds_read_b128 for
 // this access pattern), double-buffered, register-staged one step ahead like the generic kernel.
-#include "daam_tap_common.h"
+#include "daam_tap16.h"
 
 namespace daam {
-
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-constexpr int kD64Row = 160;                       // bytes per K row in LDS (128 + 32 pad)
-constexpr int kD64Rows = 80;                       // 5 MFMA row tiles; rows 77..79 stay zero
-constexpr int kD64KBuf = kD64Rows * kD64Row;       // 12800
-constexpr int kSlots16 = 20;                       // token slots per lane
 
 template <typename ACC_T> constexpr size_t tap_d64_lds_bytes() {
     const size_t kb = 2 * (size_t)kD64KBuf, st = (size_t)kTok * kMfmaPixels * sizeof(ACC_T);
     return (kb > st ? kb : st) + (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);
-}
-
-// token of slot i (= 4*mt + r) for lane quarter h
-__device__ __forceinline__ constexpr int slot16_token(int i, int h) { return 16 * (i >> 2) + 4 * h + (i & 3); }
-
-// all-reduce over the four lanes (l, l^16, l^32, l^48) that share a pixel, on the VALU
-// (v_permlane16_swap / v_permlane32_swap exchange, no LDS crossbar)
-__device__ __forceinline__ float quad_max(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-// value of lane quarter 0 (lanes 0..15 = the lanes holding token 0) of each pixel, in all four of its lanes
-__device__ __forceinline__ float quad_bcast0(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);   // r[0] = rows (0, 0, 2, 2)
-    r = __builtin_amdgcn_permlane32_swap(r[0], r[0], false, false);                                    // r[0] = rows (0, 0, 0, 0)
-    return __uint_as_float(r[0]);
-}
-__device__ __forceinline__ float quad_sum(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // softmax over the 77 tokens of the lane's pixel (20 slots here, 57 in the three partner lanes)

@@ -67,6 +67,23 @@ struct ProbsLaunch {        // daam_tap_probs
     int32_t heads_kept, bh_first, hw, tokens, tiles_per_head, total_wgs, wgs_per_xcd;
 };
 
+struct AttendLaunch {       // daam_attend: one cross-attention call, every (batch, head)
+    const void* q;
+    const void* k;
+    const void* v;
+    void* out;
+    void* acc;              // the layer's running sums [heads_kept, tokens, hw], or NULL: no tap in this launch
+    int32_t batch, heads, hw, tiles_per_head, total_wgs, wgs_per_xcd;
+    int32_t bh_first;       // first tapped batch*heads index (BH/2, trace.py:240)
+    int32_t round_logits;
+    int32_t fresh;          // sums are known to be zero: write instead of read-modify-write
+    float scale;
+    int64_t q_sb, q_sh, q_sp;
+    int64_t k_sb, k_sh, k_st;
+    int64_t v_sb, v_sh, v_st;
+    int64_t o_sb, o_sh, o_sp;
+};
+
 constexpr int kFinMaxChunks = 31;
 
 // One selected (layer, head) key of a finalize launch.

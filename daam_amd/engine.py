@@ -110,6 +110,7 @@ class HeatMapEngine:
         self._window = self.defer_steps                  # steps of one layer per launch
         self._cnt: List[int] = [0] * self.n_layers      # recorded steps per layer
         self._qk_cache: List[Optional[tuple]] = [None] * self.n_layers
+        self._att_cache: List[Optional[tuple]] = [None] * self.n_layers   # attend(): per-layer call descriptors
         self._touched_flag: List[bool] = [False] * self.n_layers
         self._mask_cache: Dict[tuple, tuple] = {}        # finalize key masks per selection
         # deferred mode: the per-call bookkeeping runs in the C++ recorder (csrc/daam_fastpath.cpp) when
@@ -186,6 +187,7 @@ class HeatMapEngine:
         self.touched.clear()
         self._touched_flag = [False] * self.n_layers
         self._qk_cache = [None] * self.n_layers
+        self._att_cache = [None] * self.n_layers
         if self._fast is not None:
             self._fast.invalidate()
         self._drop_recorded()
@@ -241,6 +243,7 @@ class HeatMapEngine:
             # (heatmap.py:170-172): leave the old buffers to those views and start the next generation on new ones
             self.acc, self.layer_info = {}, {}
             self._qk_cache = [None] * self.n_layers
+            self._att_cache = [None] * self.n_layers
             self._mask_cache.clear()
             if self._fast is not None:
                 self._fast.invalidate()
@@ -351,6 +354,66 @@ class HeatMapEngine:
                  (query.numel() + key.numel()) * query.element_size())
         self._qk_cache[layer] = entry
         return query, key, entry
+
+    # ---- attend: the processor's attention on the library's kernel, tap fused in -------------------
+    def attend(self, layer: int, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, heads: int, scale: float,
+               factor: int, round_logits: bool = True, tapped: bool = True) -> Optional[torch.Tensor]:
+        """``softmax(scale * Q K^T) V`` of one cross-attention call with the reference's rounding points
+        (``get_attention_scores`` + ``bmm``, daam/trace.py:276,296-297) on ``daam_attend``; returns ``[B, hw, heads*d]``
+        ready for the output projection, or ``None`` when the call is not one the kernel takes (not fp16 / head_dim 64 /
+        77 keys / contiguous): the caller then uses the framework's attention and ``tap_qk``.
+
+        ``tapped``: the call passes the reference's gate (trace.py:289).  On an immediate trace (``defer_steps=0``) the
+        heat-map update happens inside the same kernel; on a deferred trace the kernel only attends and Q / K are
+        recorded for the batched launch, exactly as ``tap_qk`` would."""
+        a = self._att_cache[layer] if 0 <= layer < self.n_layers else None
+        if (a is None or a[0] != query.shape or a[1] != key.shape or a[2] is not query.dtype or a[3] != heads
+                or a[4] != scale or a[5] != round_logits):
+            a = self._prepare_attend(layer, query, key, value, heads, scale, round_logits)
+        if (a[6] is None or value.shape != a[1] or key.dtype is not a[2] or value.dtype is not a[2]
+                or not (query.is_contiguous() and key.is_contiguous() and value.is_contiguous())):
+            return None
+        fused_tap = tapped and not self.defer_steps
+        if fused_tap:
+            c = self._qk_cache[layer]
+            if (c is None or c[0] != query.shape or c[1] != key.shape or c[2] is not query.dtype or c[3] != heads
+                    or c[4] != scale or c[5] != round_logits or c[6] != factor):
+                self._prepare_qk(layer, query, key, heads, scale, factor, round_logits)    # validates, configures the layer
+        out = torch.empty_like(query)
+        rc = self.lib.daam_attend(self.ctx, layer, query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),
+                                  a[6], 1 if fused_tap else 0, self.stream)
+        if rc:
+            if rc == nat.E_UNSUPPORTED:                    # e.g. a view whose data pointer is not 16-byte aligned
+                return None
+            nat.check(rc)
+        if fused_tap:
+            if not self._touched_flag[layer]:
+                self._touch(layer)
+        elif tapped:
+            self.tap_qk(layer, query, key, heads, scale, factor, round_logits)
+        return out
+
+    def _prepare_attend(self, layer, query, key, value, heads, scale, round_logits):
+        if not 0 <= layer < self.n_layers:
+            raise IndexError(f'layer {layer} out of range (trace has {self.n_layers} layers)')
+        self._require_device(query)
+        ref = None
+        desc = None
+        if (query.dtype is torch.float16 and query.dim() == 3 and key.dim() == 3 and key.shape[1] == self.tokens
+                and query.shape[2] == heads * 64 and key.shape[2] == heads * 64 and query.shape[0] == key.shape[0]):
+            self._ensure_ctx(query.dtype)
+            if self.acc_dtype in (torch.float16, torch.float32):
+                b, hw, c = query.shape
+                qk = nat.QKDesc(in_dtype=nat.DAAM_F16, batch=b, heads=heads, hw=hw, tokens=self.tokens, head_dim=64,
+                                round_logits=1 if round_logits else 0, scale=float(scale),
+                                q_stride_b=hw * c, q_stride_h=64, q_stride_p=c,
+                                k_stride_b=self.tokens * c, k_stride_h=64, k_stride_t=c)
+                desc = nat.AttendDesc(qk=qk, v_stride_b=self.tokens * c, v_stride_h=64, v_stride_t=c,
+                                      o_stride_b=hw * c, o_stride_h=64, o_stride_p=c)
+                ref = nat.byref(desc)
+        entry = (query.shape, key.shape, query.dtype, heads, scale, round_logits, ref, desc)
+        self._att_cache[layer] = entry
+        return entry
 
     def _launch_stream(self):
         """The stream a deferred launch goes to, ordered after the producers of the recorded Q / K: normally the

@@ -240,6 +240,9 @@ class UNetCrossAttentionHooker(ObjectHooker):
         self._fusable = (self.trace.tap_mode == 'qk' and not self.save_heads and not self.load_heads
                          and not getattr(attn, 'upcast_softmax', False))
         self._tap_qk = self.trace.engine.tap_qk           # the C++ recorder's entry point on a deferred trace
+        # attention itself on the library's kernel (fp16, head_dim 64, 77 keys), with the tap fused in on an immediate
+        # trace; DAAM_NO_ATTEND=1 keeps the framework's fused SDPA for the model's output
+        self._attend = None if os.environ.get('DAAM_NO_ATTEND') else self.trace.engine.attend
         attn.set_processor(self)
 
     def _unhook_impl(self):
@@ -276,7 +279,12 @@ class UNetCrossAttentionHooker(ObjectHooker):
         self.trace._gen_idx += 1
         batch, positions, channels = query.shape
         factor = self._factor(positions)
-        if factor != 8 and key.shape[1] == self.context_size:
+        tapped = factor != 8 and key.shape[1] == self.context_size          # trace.py:289
+        if self._attend is not None and key.shape[1] == self.context_size:
+            out = self._attend(self.layer_idx, query, key, value, self._heads, self._scale, factor, self._round_logits, tapped)
+            if out is not None:
+                return out
+        if tapped:
             self._tap_qk(self.layer_idx, query, key, self._heads, self._scale, factor, self._round_logits)
         heads = self._heads
         head_dim = channels // heads

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DAAM_ABI_VERSION 2
+#define DAAM_ABI_VERSION 3
 
 /* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
 #define DAAM_API __attribute__((visibility("default")))
@@ -124,6 +124,28 @@ DAAM_API int daam_tap_pending(DaamCtx* ctx, int* n_calls, int* max_steps);
 DAAM_API int daam_tap_flush(DaamCtx* ctx, void* stream);
 DAAM_API int daam_tap_probs(DaamCtx* ctx, int layer, const void* probs, int in_dtype, int batch_heads,
                    int hw, int tokens, void* stream);
+
+/* ---- attend: the processor's attention with the tap fused in ---------------------------------
+ * One cross-attention call of the reference's processor between the projections (daam/trace.py:262-270) and the
+ * output projection (:300-302):  out = softmax(scale * Q K^T) V  for every (batch, head) -- get_attention_scores
+ * (daam/trace.py:276) and torch.bmm(probs, value) + batch_to_head_dim (:296-297), with their rounding points: logits and
+ * probabilities rounded to the pipeline dtype, the value product accumulated in f32 and rounded once -- and, when
+ * `tap` != 0, the heat-map update of the same call (the per-head loop daam/trace.py:289-294, heatmap.py:153-156) from
+ * the same probabilities, in the same kernel launch: nothing [B*H, hw, 77]-sized exists, Q is read once, no Q / K
+ * has to stay alive after the call.  `tap` = 0 leaves the layer's sums alone (the caller records q, k for a deferred
+ * daam_tap_qk_enqueue, or the call is not tapped: reference gate daam/trace.py:289).
+ * v is [batch, tokens, heads * head_dim] like k; out is written as [batch, hw, heads * head_dim] in the given strides
+ * (ELEMENTS; head_dim contiguous).  Supported: DAAM_F16, head_dim 64, tokens 77, strides multiples of 8, 16-byte aligned
+ * pointers (every SDXL / SD-2.x cross-attention) -- daam_attend_supported() tells; otherwise DAAM_E_UNSUPPORTED and the
+ * caller uses its framework's attention plus daam_tap_qk. */
+typedef struct DaamAttendDesc {
+    DaamQKDesc qk;
+    int64_t v_stride_b, v_stride_h, v_stride_t;
+    int64_t o_stride_b, o_stride_h, o_stride_p;
+} DaamAttendDesc;
+DAAM_API int daam_attend_supported(const DaamAttendDesc* d, const void* q, const void* k, const void* v, const void* out);
+DAAM_API int daam_attend(DaamCtx* ctx, int layer, const void* q, const void* k, const void* v, void* out,
+                         const DaamAttendDesc* d, int tap, void* stream);
 
 /* ---- finalize ---------------------------------------------------------------------------
  * compute_global_heat_map (trace.py:103-126) over the keys selected by `key_mask`:

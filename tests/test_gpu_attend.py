@@ -1,0 +1,150 @@
+"""``daam_attend`` (include/daam_hip.h): the processor's attention -- ``get_attention_scores`` + ``bmm`` +
+``batch_to_head_dim`` of the reference's ``UNetCrossAttentionHooker.__call__`` (daam/trace.py:276,296-297) -- with the
+heat-map tap (:289-294, heatmap.py:153-156) fused into the same kernel.  Checked against
+
+* a float64 restatement with the reference's rounding points (numpy, this file: logits -> fp16, softmax, probabilities ->
+  fp16, value product in high precision -> fp16),
+* the reference's own sequence of torch ops run in PyTorch-ROCm eager on the same inputs (``oracle/torch_hooks.py``),
+* the library's stand-alone tap (``daam_tap_qk``): the fused tap must leave BIT-IDENTICAL running sums.
+
+Run with ``-m gpu`` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_hooks as th
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _inputs(batch, heads, hw, seed, gain=1.0, dtype=torch.float16):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    c = heads * 64
+    q = (torch.randn(batch, hw, c, generator=g) * gain).to(dtype).to(DEV)
+    k = torch.randn(batch, 77, c, generator=g)
+    k[:, 0] *= 3.0                                         # start-of-text dominance, like real cross-attention
+    k = (k * gain).to(dtype).to(DEV)
+    v = torch.randn(batch, 77, c, generator=g).to(dtype).to(DEV)
+    return q, k, v
+
+
+def _to_heads(t, heads):                                   # diffusers head_to_batch_dim
+    b, s, c = t.shape
+    return t.reshape(b, s, heads, c // heads).permute(0, 2, 1, 3).reshape(b * heads, s, c // heads)
+
+
+def _from_heads(t, heads):                                 # diffusers batch_to_head_dim
+    bh, s, d = t.shape
+    return t.reshape(bh // heads, heads, s, d).permute(0, 2, 1, 3).reshape(bh // heads, s, d * heads)
+
+
+def _reference_eager(q, k, v, heads, scale):
+    """The reference's processor between the projections: trace.py:272-276, 296-297 (torch ops, on the GPU)."""
+    qh, kh, vh = (_to_heads(t, heads) for t in (q, k, v))
+    probs = th.attention_probs(qh, kh, scale)
+    return _from_heads(torch.bmm(probs, vh), heads), probs
+
+
+def _restated_f64(q, k, v, heads, scale, round_logits=True):
+    """float64 arithmetic, the reference's rounding points."""
+    qh, kh, vh = (_to_heads(t, heads).cpu().numpy().astype(np.float64) for t in (q, k, v))
+    logits = np.einsum('bpd,btd->bpt', qh, kh).astype(np.float32) * np.float32(scale)      # f32 accumulate, alpha in f32
+    if round_logits:
+        logits = logits.astype(np.float16)
+    x = logits.astype(np.float64)
+    e = np.exp(x - x.max(-1, keepdims=True))
+    probs = (e / e.sum(-1, keepdims=True)).astype(np.float16)
+    out = np.einsum('bpt,btd->bpd', probs.astype(np.float64), vh).astype(np.float16)
+    return _from_heads(torch.from_numpy(out), heads), probs
+
+
+def _engine(n_layers=1, accumulate='exact', defer_steps=0):
+    from daam_amd.engine import HeatMapEngine
+    return HeatMapEngine(n_layers, defer_steps=defer_steps, accumulate=accumulate)
+
+
+@pytest.mark.parametrize('batch,heads,hw', [(2, 10, 4096), (2, 20, 1024), (2, 3, 576), (1, 4, 64), (2, 2, 16384)])
+def test_attend_output_matches_reference(batch, heads, hw):
+    q, k, v = _inputs(batch, heads, hw, seed=hw + heads)
+    eng = _engine()
+    out = eng.attend(0, q, k, v, heads, 0.125, 1, True, tapped=False)
+    assert out is not None and out.shape == q.shape and out.dtype == torch.float16
+    want_eager, _ = _reference_eager(q, k, v, heads, 0.125)
+    scale_v = want_eager.float().abs().max().item()
+    err_eager = (out.float() - want_eager.float()).abs().max().item()
+    # fp16 rounding of the output (2^-11 relative) + an fp16-boundary flip of a logit now and then (summation order)
+    assert err_eager <= 2e-3 * scale_v, f'vs the reference ops in eager: {err_eager / scale_v:.2e}'
+    if hw <= 4096:
+        want, _ = _restated_f64(q, k, v, heads, 0.125)
+        err = (out.float().cpu() - want.float()).abs()
+        assert err.max().item() <= 2e-3 * scale_v
+        # ... and nearly everywhere the two agree to the last fp16 bit or one ulp
+        ulp = np.spacing(np.abs(want.numpy()).astype(np.float16)).astype(np.float64)
+        assert (err.numpy() <= ulp).mean() >= 0.995
+    eng.close()
+
+
+@pytest.mark.parametrize('accumulate', ['exact', 'float32'])
+@pytest.mark.parametrize('batch,heads,hw', [(2, 10, 4096), (2, 5, 1024), (1, 4, 256), (2, 3, 576)])
+def test_fused_tap_leaves_the_sums_of_the_stand_alone_tap(batch, heads, hw, accumulate):
+    steps = 3
+    fused, plain = _engine(accumulate=accumulate), _engine(accumulate=accumulate)
+    for step in range(steps):
+        q, k, v = _inputs(batch, heads, hw, seed=100 * step + heads)
+        out = fused.attend(0, q, k, v, heads, 0.125, 1, True, tapped=True)
+        assert out is not None
+        plain.tap_qk(0, q, k, heads, 0.125, 1, True)
+        want, _ = _reference_eager(q, k, v, heads, 0.125)
+        assert (out.float() - want.float()).abs().max().item() <= 2e-3 * want.float().abs().max().item()
+    a, b = dict(fused.items()), dict(plain.items())
+    assert list(a) == list(b) and len(a) == (batch * heads - (batch * heads) // 2)
+    for key in a:
+        assert a[key].dtype == b[key].dtype
+        assert torch.equal(a[key], b[key]), f'{key}: fused and stand-alone tap differ'
+    # and the sums are the reference's: probabilities of the kept heads, summed over the steps in the sum dtype
+    q, k, v = _inputs(batch, heads, hw, seed=heads)        # step 0 again
+    _, probs = _reference_eager(q, k, v, heads, 0.125)
+    one = _engine(accumulate=accumulate)
+    one.attend(0, q, k, v, heads, 0.125, 1, True, tapped=True)
+    side = int(hw ** 0.5)
+    kept = probs[probs.shape[0] // 2:]                                       # trace.py:240
+    got = torch.stack([t for _, t in one.items()]).float()                   # [kept heads, 77, side, side]
+    want = kept.permute(0, 2, 1).reshape(kept.shape[0], 77, side, side).float()
+    diff = (got - want).abs()
+    assert diff.max().item() <= 2.0 ** -6 * want.max().item() + 1e-3        # a flipped fp16 logit: e^(2^-6) - 1 relative
+    assert (diff > 0).float().mean().item() <= 0.02
+    for e in (fused, plain, one):
+        e.close()
+
+
+def test_attend_unrounded_logits_and_general_scale():
+    """``upcast_attention`` (logits stay f32) and a scale that is not a power of two take the exact-softmax variants."""
+    q, k, v = _inputs(2, 4, 1024, seed=5)
+    eng = _engine()
+    for round_logits, scale in ((False, 0.125), (True, 0.11)):
+        out = eng.attend(0, q, k, v, 4, scale, 1, round_logits, tapped=False)
+        want, _ = _restated_f64(q, k, v, 4, scale, round_logits)
+        assert (out.float().cpu() - want.float()).abs().max().item() <= 2e-3 * want.float().abs().max().item()
+    eng.close()
+
+
+def test_attend_declines_what_the_kernel_does_not_take():
+    eng = _engine()
+    q, k, v = _inputs(2, 4, 256, seed=1)
+    assert eng.attend(0, q.float(), k.float(), v.float(), 4, 0.125, 1, True, tapped=False) is None        # fp32 pipeline
+    assert eng.attend(0, q[:, :, :128], k[:, :, :128], v[:, :, :128], 4, 32 ** -0.5, 1, True, tapped=False) is None  # head_dim 32
+    assert eng.attend(0, q, k[:, :64], v[:, :64], 4, 0.125, 1, True, tapped=False) is None                # 64 keys
+    assert eng.attend(0, q.transpose(0, 1).contiguous().transpose(0, 1), k, v, 4, 0.125, 1, True, tapped=False) is None
+    assert eng.attend(0, q, k, v, 4, 0.125, 1, True, tapped=False) is not None
+    eng.close()
+
+
+def test_extreme_logits_take_the_row_maximum_path():
+    q, k, v = _inputs(2, 2, 256, seed=9, gain=6.0)         # logits of a few hundred: 2^((x - x0) L) overflows for some rows
+    eng = _engine()
+    out = eng.attend(0, q, k, v, 2, 0.125, 1, True, tapped=False)
+    assert torch.isfinite(out).all()
+    want, _ = _restated_f64(q, k, v, 2, 0.125)
+    assert (out.float().cpu() - want.float()).abs().max().item() <= 4e-3 * want.float().abs().max().item()
+    eng.close()
