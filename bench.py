@@ -538,6 +538,10 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_integrated and world == 1 and args.workload == 'sdxl1024':
             extra['integrated'] = integrated_overhead(device)
+            # the processor's attention on daam_attend (tools/attend_bench.py): per denoising step of 60 layer calls, next
+            # to torch's fused SDPA, and the cost of the in-kernel tap of an immediate (defer_steps=0) trace
+            from tools.attend_bench import measure as attend_measure
+            extra['attend'] = attend_measure(steps=20, reps=3, dev=device)
         cpu = None
         if not args.no_baselines and world == 1:
             cpu = cpu_baseline(wl['kind'], wl['latent'], args.denoise_steps, eager_device=device)

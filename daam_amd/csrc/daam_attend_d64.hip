@@ -159,6 +159,25 @@ __global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L
         qreg[g][0] = *as_global<half8>(row + (8 * h) * 2);
         qreg[g][1] = *as_global<half8>(row + (32 + 8 * h) * 2);
     }
+    // the tap's read-modify-write: this thread's 16-byte pieces of the running sums are fetched NOW, so that their HBM
+    // latency runs under the two MFMA stages instead of behind them
+    constexpr int APC = (kTok * (kMfmaPixels / 8) + 255) / 256;            // pieces per thread (5)
+    constexpr int AVEC = sizeof(ACC_T) == 2 ? 1 : 2;                       // 16-byte loads per piece
+    const bool tap = L.acc != nullptr && bh >= L.bh_first;                 // workgroup-uniform
+    ACC_T* acc = reinterpret_cast<ACC_T*>(L.acc) + (tap ? (size_t)(bh - L.bh_first) * kTok * L.hw : 0);
+    float4v areg[APC][AVEC];
+#pragma unroll
+    for (int a = 0; a < APC; ++a) {
+        const int piece = tid + 256 * a;
+        const int row = piece >> 4, col = (piece & 15) * 8;
+#pragma unroll
+        for (int u = 0; u < AVEC; ++u) areg[a][u] = float4v{0, 0, 0, 0};
+        if (tap && !L.fresh && row < kTok && p0 + col < L.hw) {
+            const ACC_T* src = acc + (size_t)row * L.hw + p0 + col;
+#pragma unroll
+            for (int u = 0; u < AVEC; ++u) areg[a][u] = *as_global<float4v>(src + 4 * u);
+        }
+    }
     for (int i = tid; i < 3 * (kD64Row / 16); i += 256)       // K rows 77..79 take part in the MFMAs: finite
         *reinterpret_cast<float4v*>(kbuf + kTok * kD64Row + i * 16) = float4v{0, 0, 0, 0};
     for (int i = tid; i < kVBuf / 16; i += 256)               // key slots 77..95 of V^T meet p = 0: must not be NaN / inf
@@ -195,7 +214,6 @@ __global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L
     softmax20_probs<FAST_EXP>(c1, L.scale, L.round_logits, h, ph[1]);
 
     // ---- tap: probabilities of the kept heads -> LDS tile [token][pixel] ------------------------------------------
-    const bool tap = L.acc != nullptr && bh >= L.bh_first;     // workgroup-uniform
     if (tap) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -238,24 +256,20 @@ __global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L
     // ---- tap: sums[kept head][token][pixel] += p, 16-byte row pieces -----------------------------------------------
     if (tap) {
         __syncthreads();
-        ACC_T* acc = reinterpret_cast<ACC_T*>(L.acc) + (size_t)(bh - L.bh_first) * kTok * L.hw;
-        for (int piece = tid; piece < kTok * (kMfmaPixels / 8); piece += 256) {
+#pragma unroll
+        for (int a = 0; a < APC; ++a) {
+            const int piece = tid + 256 * a;
             const int row = piece >> 4, col = (piece & 15) * 8;
-            if (p0 + col >= L.hw) continue;
+            if (row >= kTok || p0 + col >= L.hw) continue;
             const half8 pv = *reinterpret_cast<const half8*>(stage + row * kMfmaPixels + col);
             ACC_T* dst = acc + (size_t)row * L.hw + p0 + col;
             if constexpr (sizeof(ACC_T) == 2) {
-                half8 a = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (!L.fresh) a = *as_global<half8>(dst);
-                a += pv;                                                 // heatmap.py:156 in fp16 (v_pk_add_f16)
-                *as_global_rw<half8>(dst) = a;
+                half8 sum = __builtin_bit_cast(half8, areg[a][0]);
+                sum += pv;                                               // heatmap.py:156 in fp16 (v_pk_add_f16)
+                *as_global_rw<half8>(dst) = sum;
             } else {
-                float4v a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-                if (!L.fresh) { a0 = *as_global<float4v>(dst); a1 = *as_global<float4v>(dst + 4); }
-                a0 += float4v{(float)pv[0], (float)pv[1], (float)pv[2], (float)pv[3]};
-                a1 += float4v{(float)pv[4], (float)pv[5], (float)pv[6], (float)pv[7]};
-                *as_global_rw<float4v>(dst) = a0;
-                *as_global_rw<float4v>(dst + 4) = a1;
+                *as_global_rw<float4v>(dst) = areg[a][0] + float4v{(float)pv[0], (float)pv[1], (float)pv[2], (float)pv[3]};
+                *as_global_rw<float4v>(dst + 4) = areg[a][1] + float4v{(float)pv[4], (float)pv[5], (float)pv[6], (float)pv[7]};
             }
         }
     }

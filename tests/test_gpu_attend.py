@@ -148,3 +148,38 @@ def test_extreme_logits_take_the_row_maximum_path():
     want, _ = _restated_f64(q, k, v, 2, 0.125)
     assert (out.float().cpu() - want.float()).abs().max().item() <= 4e-3 * want.float().abs().max().item()
     eng.close()
+
+
+def test_processor_routes_leave_identical_sums(monkeypatch):
+    """Through ``daam_amd.trace`` on an SDXL-shaped (head_dim 64, fp16) stack: deferred trace (daam_attend + batched tap),
+    immediate trace (tap fused into daam_attend) and the framework-attention route (``DAAM_NO_ATTEND=1``: torch SDPA +
+    batched tap) must leave bit-identical running sums (hence the same global heat maps); the hidden states of the two attention
+    kernels agree to fp16 accuracy."""
+    import daam_amd
+    from oracle import fake_diffusers as fd
+    pipe = fd.make_pipe('sdxl', device=DEV, dtype=torch.float16, batch=2, seed=41, mini=True, identity_proj=False,
+                        dim_head=64, heads_scale=0.2, tblocks_cap=1)
+    pipe.keep_outputs = True
+
+    def run(**kw):
+        with daam_amd.trace(pipe, **kw) as tc:
+            pipe('a photo of a monkey', num_inference_steps=4)
+            used = [h._attend is not None for h in tc.module if hasattr(h, '_attend')]
+            raw = [(k, v.clone()) for k, v in tc.all_heat_maps]
+            return raw, tc.compute_global_heat_map().heat_maps.clone(), [o.clone() for o in pipe.last_outputs], used
+
+    deferred = run(defer_steps=64)
+    immediate = run(defer_steps=0)
+    monkeypatch.setenv('DAAM_NO_ATTEND', '1')
+    stock = run(defer_steps=64)
+    assert all(deferred[3]) and all(immediate[3]) and not any(stock[3])
+    for other in (immediate, stock):
+        assert [k for k, _ in other[0]] == [k for k, _ in deferred[0]]
+        for (k, a), (_, b) in zip(deferred[0], other[0]):
+            assert torch.equal(a, b), k
+        # the finalize reduces its key chunks with f32 atomics: equal sums give equal maps up to the order of those adds
+        assert (deferred[1] - other[1]).abs().max().item() <= 1e-6 * max(1.0, deferred[1].max().item())
+    for a, b in zip(deferred[2], immediate[2]):
+        assert torch.equal(a, b)
+    for a, b in zip(deferred[2], stock[2]):
+        assert (a.float() - b.float()).abs().max().item() <= 2e-3 * b.float().abs().max().item()

@@ -225,7 +225,7 @@ def test_integrated_overhead_sdxl(sdxl_stack):
                   extraction_overhead_ms_per_step=round(overhead * 1e3, 3),
                   reference_style_eager_ms_per_step=round(t_ref / ref_steps * 1e3, 3),
                   reference_style_overhead_ms_per_step=round(ref_overhead * 1e3, 3),
-                  overhead_ratio_reference_over_daam_amd=round(ref_overhead / max(overhead, 1e-9), 1))
+                  overhead_ratio_reference_over_daam_amd=round(ref_overhead / overhead, 1) if overhead > 0 else None)
     print(json.dumps(report))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     os.makedirs(out_dir, exist_ok=True)
