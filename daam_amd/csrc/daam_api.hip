@@ -593,7 +593,7 @@ int daam_attend(DaamCtx* c, int layer, const void* q, const void* k, const void*
 {
     if (!c || !d || !q || !k || !v || !out) return fail(DAAM_E_INVALID, "NULL argument");
     if (!daam_attend_supported(d, q, k, v, out))
-        return fail(DAAM_E_UNSUPPORTED, "daam_attend: fp16, head_dim 64, 77 tokens, strides %% 8 == 0, 16-byte aligned pointers only");
+        return fail(DAAM_E_UNSUPPORTED, "daam_attend: fp16, head_dim %% 8 == 0 up to 160, 77 tokens, strides %% 8 == 0, 16-byte aligned pointers only");
     if (d->qk.tokens != c->tokens) return fail(DAAM_E_INVALID, "tokens %d != context size %d", d->qk.tokens, c->tokens);
     if (tap) {
         int rc = check_qk(c, layer, q, k, &d->qk);
@@ -604,7 +604,7 @@ int daam_attend(DaamCtx* c, int layer, const void* q, const void* k, const void*
     AttendLaunch L;
     memset(&L, 0, sizeof L);
     L.q = q; L.k = k; L.v = v; L.out = out;
-    L.batch = d->qk.batch; L.heads = d->qk.heads; L.hw = d->qk.hw;
+    L.batch = d->qk.batch; L.heads = d->qk.heads; L.hw = d->qk.hw; L.head_dim = d->qk.head_dim;
     L.tiles_per_head = (d->qk.hw + tap_mfma_tile_pixels() - 1) / tap_mfma_tile_pixels();
     L.total_wgs = L.batch * L.heads * L.tiles_per_head;
     L.wgs_per_xcd = (L.total_wgs + 7) / 8;

@@ -1,7 +1,7 @@
 // Cross-attention of one UNet layer call with the heat-map tap fused in: out = softmax(scale Q K^T) V for every
 // (batch, head), and -- for the kept (conditional) heads, when the launch carries the layer's running sums -- sums += P
-// from the SAME fp16 probabilities, in one kernel.  fp16 pipeline, head_dim 64, 77 keys (every SDXL / SD-2.x
-// cross-attention), gfx950, v_mfma_f32_16x16x32_f16.
+// from the SAME fp16 probabilities, in one kernel.  fp16 pipeline, 77 keys, head_dim a multiple of 8 up to 160 (SDXL /
+// SD-2.x: 64; SD-v1.5: 40 / 80 / 160; contraction zero-padded to the next multiple of 32), gfx950, v_mfma_f32_16x16x32_f16.
 //
 // Replaces, inside the reference's attention processor, get_attention_scores (daam/trace.py:276; diffusers 0.21.2:
 // baddbmm -> fp16 logits -> f32 softmax -> fp16 probabilities), the per-head update loop (daam/trace.py:289-294 with
@@ -15,16 +15,13 @@
 // order (v_slot_byte), so the probabilities never leave the registers between the two MFMA stages.  O^T tile: lane holds
 // pixel l&15 and 4 consecutive head_dim elements -> one 8-byte store into out[batch, pixel, head*64 + ...], the
 // [batch, hw, heads*64] layout the output projection consumes (no transpose / reshape copy afterwards).
-// LDS: K [80 rows][160 B] (A operand of S^T), V^T [64 rows][96 key slots, 208 B] (A operand of O^T), and for the tap a
-// [77][128] fp16 tile of probabilities that turns the lanes' scattered 2-byte values into 16-byte row pieces of the sums.
+// LDS (head_dim 64): K [80 rows][160 B] (A operand of S^T), V^T [64 rows][96 key slots, 208 B] (A operand of O^T), and for the
+// tap a [77][128] fp16 tile of probabilities that turns the lanes' scattered 2-byte values into 16-byte row pieces of the sums.
 #include "daam_tap16.h"
 
 namespace daam {
 
 constexpr int kVRow = 208;                         // bytes per V^T row: 96 key slots x 2 B + 16 pad (13 x 16 B: conflict-free b128 rows)
-constexpr int kVBuf = 64 * kVRow;                  // 13312
-constexpr int kStageOff = kD64KBuf + kVBuf;        // probabilities tile of the tap
-constexpr int kAttendLds = kStageOff + kTok * kMfmaPixels * 2;     // 45824
 
 // byte offset of key `t` inside a V^T row: k-block kb = t / 32 of the second product, lane quarter x / 4 supplies slots
 // 8*(x/4) + e, e < 4 from S^T row tile 2 kb (tokens 32 kb + ..), e >= 4 from row tile 2 kb + 1 (tokens 32 kb + 16 + ..)
@@ -121,14 +118,27 @@ __device__ __forceinline__ void softmax20_probs(const floatx4 (&c)[5], float sca
     }
 }
 
-template <typename ACC_T, bool FAST_EXP>
-__global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L)
+// KS = 32-wide k-steps of the first product (head_dim <= 32 KS, zero-padded), DT = 16-row tiles of the output's head_dim
+// (2, 4: head_dim <= 64 -- SDXL / SD-2.x 64, SD-v1.5 40;  3, 6: <= 96 -- SD-v1.5 80;  5, 10: <= 160 -- SD-v1.5 160)
+template <int KS, int DT> struct AttendShape {
+    static constexpr int kKRow = KS * 64 + 32;                 // bytes per K row in LDS (+32: conflict-free b128 operand reads)
+    static constexpr int kKBuf = kD64Rows * kKRow;
+    static constexpr int kVBuf = DT * 16 * kVRow;
+    static constexpr int kStageOff = kKBuf + kVBuf;            // probabilities tile of the tap
+    static constexpr int kLds = kStageOff + kTok * kMfmaPixels * 2;
+    static constexpr int kPieces = KS * 4;                     // 16-byte pieces per K / V row
+    static constexpr int kKCh = (kTok * kPieces + 255) / 256;  // pieces per thread
+};
+
+template <typename ACC_T, bool FAST_EXP, int KS, int DT>
+__global__ __launch_bounds__(256, 2) void attend_kernel(const AttendLaunch L)
 {
-    constexpr int KCH = (kTok * 8 + 255) / 256;               // 16-byte K (and V) pieces per thread (3)
+    using S = AttendShape<KS, DT>;
+    constexpr int KCH = S::kKCh;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* kbuf = smem;
-    unsigned char* vbuf = smem + kD64KBuf;
-    _Float16* stage = reinterpret_cast<_Float16*>(smem + kStageOff);
+    unsigned char* vbuf = smem + S::kKBuf;
+    _Float16* stage = reinterpret_cast<_Float16*>(smem + S::kStageOff);
 
     const int wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
     if (wg < 0) return;
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L
     const int b = bh / L.heads, hd = bh - b * L.heads;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, h = lane >> 4;
+    const int d = L.head_dim;                                  // multiple of 8, <= 32 KS and <= 16 DT
 
     // ---- global fetches first (K, V pieces; this lane's Q pieces), LDS zero-fill underneath ------------------------
     const char* kp = reinterpret_cast<const char*>(L.k) + (b * L.k_sb + hd * L.k_sh) * 2;
@@ -147,17 +158,22 @@ __global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L
 #pragma unroll
     for (int j2 = 0; j2 < KCH; ++j2) {
         const int c = tid + 256 * j2;
-        const int t = min(c >> 3, kTok - 1), ch = c & 7;
-        kreg[j2] = *as_global<float4v>(kp + ((int64_t)t * L.k_st + ch * 8) * 2);
-        vreg[j2] = *as_global<float4v>(vp + ((int64_t)t * L.v_st + ch * 8) * 2);
+        const int t = min(c / S::kPieces, kTok - 1), ch = c % S::kPieces;
+        const int e = ch * 8 < d ? ch * 8 : 0;                 // pieces past head_dim: a valid address, never committed
+        kreg[j2] = *as_global<float4v>(kp + ((int64_t)t * L.k_st + e) * 2);
+        vreg[j2] = *as_global<float4v>(vp + ((int64_t)t * L.v_st + e) * 2);
     }
     const int px[2] = {p0 + wave * 32 + j, p0 + wave * 32 + 16 + j};
-    half8 qreg[2][2];
+    half8 qreg[2][KS];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const char* row = qp + (int64_t)min(px[g], L.hw - 1) * L.q_sp * 2;
-        qreg[g][0] = *as_global<half8>(row + (8 * h) * 2);
-        qreg[g][1] = *as_global<half8>(row + (32 + 8 * h) * 2);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int e = 32 * ks + 8 * h;
+            qreg[g][ks] = *as_global<half8>(row + (e < d ? e : 0) * 2);
+            if (e >= d) qreg[g][ks] = half8{0, 0, 0, 0, 0, 0, 0, 0};       // zero-padded contraction
+        }
     }
     // the tap's read-modify-write: this thread's 16-byte pieces of the running sums are fetched NOW, so that their HBM
     // latency runs under the two MFMA stages instead of behind them
@@ -178,17 +194,22 @@ __global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L
             for (int u = 0; u < AVEC; ++u) areg[a][u] = *as_global<float4v>(src + 4 * u);
         }
     }
-    for (int i = tid; i < 3 * (kD64Row / 16); i += 256)       // K rows 77..79 take part in the MFMAs: finite
-        *reinterpret_cast<float4v*>(kbuf + kTok * kD64Row + i * 16) = float4v{0, 0, 0, 0};
-    for (int i = tid; i < kVBuf / 16; i += 256)               // key slots 77..95 of V^T meet p = 0: must not be NaN / inf
-        *reinterpret_cast<float4v*>(vbuf + i * 16) = float4v{0, 0, 0, 0};
+    // K rows 77..79 and (head_dim < 32 KS) the padding columns take part in the MFMAs: finite.  Key slots 77..95 of V^T
+    // meet p = 0, rows past head_dim are computed and dropped: must not be NaN / inf either.
+    if (d < 32 * KS) {
+        for (int i = tid; i < S::kKBuf / 16; i += 256) *reinterpret_cast<float4v*>(kbuf + i * 16) = float4v{0, 0, 0, 0};
+    } else {
+        for (int i = tid; i < 3 * (S::kKRow / 16); i += 256)
+            *reinterpret_cast<float4v*>(kbuf + kTok * S::kKRow + i * 16) = float4v{0, 0, 0, 0};
+    }
+    for (int i = tid; i < S::kVBuf / 16; i += 256) *reinterpret_cast<float4v*>(vbuf + i * 16) = float4v{0, 0, 0, 0};
     __syncthreads();
 #pragma unroll
     for (int j2 = 0; j2 < KCH; ++j2) {
         const int c = tid + 256 * j2;
-        const int t = c >> 3, ch = c & 7;
-        if (t < kTok) {
-            *reinterpret_cast<float4v*>(kbuf + t * kD64Row + ch * 16) = kreg[j2];
+        const int t = c / S::kPieces, ch = c % S::kPieces;
+        if (t < kTok && ch * 8 < d) {
+            *reinterpret_cast<float4v*>(kbuf + t * S::kKRow + ch * 16) = kreg[j2];
             const half8 vv = __builtin_bit_cast(half8, vreg[j2]);
             unsigned char* col = vbuf + v_slot_byte(t) + (8 * ch) * kVRow;
 #pragma unroll
@@ -198,16 +219,18 @@ __global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L
     __syncthreads();
 
     // ---- S^T = K Q^T ----------------------------------------------------------------------------------------------
-    const unsigned char* a_rd = kbuf + j * kD64Row + h * 16;
+    const unsigned char* a_rd = kbuf + j * S::kKRow + h * 16;
     floatx4 c0[5], c1[5];
 #pragma unroll
     for (int mt = 0; mt < 5; ++mt) {
-        const half8 a0 = *reinterpret_cast<const half8*>(a_rd + mt * 16 * kD64Row);
-        const half8 a1 = *reinterpret_cast<const half8*>(a_rd + mt * 16 * kD64Row + 64);
-        c0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, qreg[0][0], floatx4{0, 0, 0, 0}, 0, 0, 0);
-        c1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, qreg[1][0], floatx4{0, 0, 0, 0}, 0, 0, 0);
-        c0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, qreg[0][1], c0[mt], 0, 0, 0);
-        c1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, qreg[1][1], c1[mt], 0, 0, 0);
+        c0[mt] = floatx4{0, 0, 0, 0};
+        c1[mt] = floatx4{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const half8 a = *reinterpret_cast<const half8*>(a_rd + mt * 16 * S::kKRow + ks * 64);
+            c0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qreg[0][ks], c0[mt], 0, 0, 0);
+            c1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qreg[1][ks], c1[mt], 0, 0, 0);
+        }
     }
     half2v ph[2][kSlots16 / 2];
     softmax20_probs<FAST_EXP>(c0, L.scale, L.round_logits, h, ph[0]);
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L
             }
     }
 
-    // ---- O^T = V^T P^T, out[batch, pixel, head*64 + d] ------------------------------------------------------------
+    // ---- O^T = V^T P^T, out[batch, pixel, head*head_dim + e] ------------------------------------------------------
     const unsigned char* v_rd = vbuf + j * kVRow + h * 16;
     _Float16* out = reinterpret_cast<_Float16*>(L.out) + b * L.o_sb + hd * L.o_sh;
     const half2v z2 = {0, 0};
@@ -239,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L
             pb[kb] = half8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < DT; ++mt) {
+            if (16 * mt >= d) break;                           // wave-uniform
             floatx4 o = {0, 0, 0, 0};
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb) {
@@ -248,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L
             }
             const half2v lo = __builtin_convertvector(float2v{o[0], o[1]}, half2v);
             const half2v hi = __builtin_convertvector(float2v{o[2], o[3]}, half2v);
-            if (px[g] < L.hw)
+            if (px[g] < L.hw && 16 * mt + 4 * h < d)
                 *as_global_rw<half4v>(out + (int64_t)px[g] * L.o_sp + 16 * mt + 4 * h) = half4v{lo[0], lo[1], hi[0], hi[1]};
         }
     }
@@ -278,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void attend_d64_kernel(const AttendLaunch L
 bool attend_d64_supported(int in_dtype, int head_dim, int tokens, const int64_t* strides, int n_strides, const void* const* ptrs,
                           int n_ptrs)
 {
-    if (in_dtype != 0 || head_dim != 64 || tokens != kTok) return false;
+    if (in_dtype != 0 || head_dim < 8 || head_dim > 160 || head_dim % 8 != 0 || tokens != kTok) return false;
     for (int i = 0; i < n_strides; ++i)
         if (strides[i] % 8 != 0 || strides[i] < 0 || strides[i] >= ((int64_t)1 << 40)) return false;
     uintptr_t bits = 0;
@@ -286,21 +310,37 @@ bool attend_d64_supported(int in_dtype, int head_dim, int tokens, const int64_t*
     return (bits & 15) == 0;
 }
 
+template <typename ACC_T, bool FAST, int KS, int DT>
+static hipError_t launch_attend_k(const AttendLaunch& L, hipStream_t stream, int grid, int* lds_out)
+{
+    constexpr int lds = AttendShape<KS, DT>::kLds;
+    *lds_out = lds;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attend_kernel<ACC_T, FAST, KS, DT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((attend_kernel<ACC_T, FAST, KS, DT>), dim3(grid), dim3(256), lds, stream, L);
+    return hipGetLastError();
+}
+
+template <typename ACC_T, bool FAST>
+static hipError_t launch_attend_shape(const AttendLaunch& L, hipStream_t stream, int grid, int* lds_out)
+{
+    if (L.head_dim <= 64) return launch_attend_k<ACC_T, FAST, 2, 4>(L, stream, grid, lds_out);
+    if (L.head_dim <= 96) return launch_attend_k<ACC_T, FAST, 3, 6>(L, stream, grid, lds_out);
+    return launch_attend_k<ACC_T, FAST, 5, 10>(L, stream, grid, lds_out);
+}
+
 hipError_t launch_attend_d64(const AttendLaunch& L, int acc_dtype, int fast_exp, hipStream_t stream, int* grid_out, int* lds_out)
 {
     const int grid = L.wgs_per_xcd * 8;
     *grid_out = grid;
-    *lds_out = kAttendLds;
-    if (acc_dtype == 0) {
-        if (fast_exp) hipLaunchKernelGGL((attend_d64_kernel<_Float16, true>), dim3(grid), dim3(256), kAttendLds, stream, L);
-        else hipLaunchKernelGGL((attend_d64_kernel<_Float16, false>), dim3(grid), dim3(256), kAttendLds, stream, L);
-    } else if (acc_dtype == 1) {
-        if (fast_exp) hipLaunchKernelGGL((attend_d64_kernel<float, true>), dim3(grid), dim3(256), kAttendLds, stream, L);
-        else hipLaunchKernelGGL((attend_d64_kernel<float, false>), dim3(grid), dim3(256), kAttendLds, stream, L);
-    } else {
-        return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
+    if (acc_dtype == 0)
+        return fast_exp ? launch_attend_shape<_Float16, true>(L, stream, grid, lds_out) : launch_attend_shape<_Float16, false>(L, stream, grid, lds_out);
+    if (acc_dtype == 1)
+        return fast_exp ? launch_attend_shape<float, true>(L, stream, grid, lds_out) : launch_attend_shape<float, false>(L, stream, grid, lds_out);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace daam

@@ -73,7 +73,7 @@ struct AttendLaunch {       // daam_attend: one cross-attention call, every (bat
     const void* v;
     void* out;
     void* acc;              // the layer's running sums [heads_kept, tokens, hw], or NULL: no tap in this launch
-    int32_t batch, heads, hw, tiles_per_head, total_wgs, wgs_per_xcd;
+    int32_t batch, heads, hw, head_dim, tiles_per_head, total_wgs, wgs_per_xcd;
     int32_t bh_first;       // first tapped batch*heads index (BH/2, trace.py:240)
     int32_t round_logits;
     int32_t fresh;          // sums are known to be zero: write instead of read-modify-write

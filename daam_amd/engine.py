@@ -360,8 +360,8 @@ class HeatMapEngine:
                factor: int, round_logits: bool = True, tapped: bool = True) -> Optional[torch.Tensor]:
         """``softmax(scale * Q K^T) V`` of one cross-attention call with the reference's rounding points
         (``get_attention_scores`` + ``bmm``, daam/trace.py:276,296-297) on ``daam_attend``; returns ``[B, hw, heads*d]``
-        ready for the output projection, or ``None`` when the call is not one the kernel takes (not fp16 / head_dim 64 /
-        77 keys / contiguous): the caller then uses the framework's attention and ``tap_qk``.
+        ready for the output projection, or ``None`` when the call is not one the kernel takes (not fp16 / head_dim not a
+        multiple of 8 up to 160 / not 77 keys / not contiguous): the caller then uses the framework's attention and ``tap_qk``.
 
         ``tapped``: the call passes the reference's gate (trace.py:289).  On an immediate trace (``defer_steps=0``) the
         heat-map update happens inside the same kernel; on a deferred trace the kernel only attends and Q / K are
@@ -399,17 +399,19 @@ class HeatMapEngine:
         self._require_device(query)
         ref = None
         desc = None
+        d = query.shape[2] // heads if query.dim() == 3 and heads > 0 else 0
         if (query.dtype is torch.float16 and query.dim() == 3 and key.dim() == 3 and key.shape[1] == self.tokens
-                and query.shape[2] == heads * 64 and key.shape[2] == heads * 64 and query.shape[0] == key.shape[0]):
+                and d * heads == query.shape[2] and key.shape[2] == query.shape[2] and query.shape[0] == key.shape[0]
+                and d % 8 == 0 and 8 <= d <= 160):
             self._ensure_ctx(query.dtype)
             if self.acc_dtype in (torch.float16, torch.float32):
                 b, hw, c = query.shape
-                qk = nat.QKDesc(in_dtype=nat.DAAM_F16, batch=b, heads=heads, hw=hw, tokens=self.tokens, head_dim=64,
+                qk = nat.QKDesc(in_dtype=nat.DAAM_F16, batch=b, heads=heads, hw=hw, tokens=self.tokens, head_dim=d,
                                 round_logits=1 if round_logits else 0, scale=float(scale),
-                                q_stride_b=hw * c, q_stride_h=64, q_stride_p=c,
-                                k_stride_b=self.tokens * c, k_stride_h=64, k_stride_t=c)
-                desc = nat.AttendDesc(qk=qk, v_stride_b=self.tokens * c, v_stride_h=64, v_stride_t=c,
-                                      o_stride_b=hw * c, o_stride_h=64, o_stride_p=c)
+                                q_stride_b=hw * c, q_stride_h=d, q_stride_p=c,
+                                k_stride_b=self.tokens * c, k_stride_h=d, k_stride_t=c)
+                desc = nat.AttendDesc(qk=qk, v_stride_b=self.tokens * c, v_stride_h=d, v_stride_t=c,
+                                      o_stride_b=hw * c, o_stride_h=d, o_stride_p=c)
                 ref = nat.byref(desc)
         entry = (query.shape, key.shape, query.dtype, heads, scale, round_logits, ref, desc)
         self._att_cache[layer] = entry

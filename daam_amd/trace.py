@@ -240,7 +240,7 @@ class UNetCrossAttentionHooker(ObjectHooker):
         self._fusable = (self.trace.tap_mode == 'qk' and not self.save_heads and not self.load_heads
                          and not getattr(attn, 'upcast_softmax', False))
         self._tap_qk = self.trace.engine.tap_qk           # the C++ recorder's entry point on a deferred trace
-        # attention itself on the library's kernel (fp16, head_dim 64, 77 keys), with the tap fused in on an immediate
+        # attention itself on the library's kernel (fp16, 77 keys, head_dim a multiple of 8 up to 160), with the tap fused in on an immediate
         # trace; DAAM_NO_ATTEND=1 keeps the framework's fused SDPA for the model's output
         self._attend = None if os.environ.get('DAAM_NO_ATTEND') else self.trace.engine.attend
         attn.set_processor(self)

@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _inputs(batch, heads, hw, seed, gain=1.0, dtype=torch.float16):
+def _inputs(batch, heads, hw, seed, gain=1.0, dtype=torch.float16, head_dim=64):
     g = torch.Generator(device='cpu').manual_seed(seed)
-    c = heads * 64
+    c = heads * head_dim
     q = (torch.randn(batch, hw, c, generator=g) * gain).to(dtype).to(DEV)
     k = torch.randn(batch, 77, c, generator=g)
     k[:, 0] *= 3.0                                         # start-of-text dominance, like real cross-attention
@@ -118,6 +118,37 @@ def test_fused_tap_leaves_the_sums_of_the_stand_alone_tap(batch, heads, hw, accu
         e.close()
 
 
+@pytest.mark.parametrize('accumulate', ['exact', 'float32'])
+@pytest.mark.parametrize('head_dim,hw', [(40, 4096), (80, 1024), (160, 256), (8, 64), (96, 576), (128, 256)])
+def test_attend_other_head_dims(head_dim, hw, accumulate):
+    """SD-v1.5's head dims (40 / 80 / 160, 8 heads) and the corners of the three kernel shapes: output against the float64
+    restatement and the reference ops, fused tap against the stand-alone tap (bit-identical where both run the 16x16x32
+    tiling, i.e. head_dim <= 64; to fp16-flip accuracy where the stand-alone tap is the 32x32x16 kernel)."""
+    heads, scale = 8, head_dim ** -0.5
+    fused, plain = _engine(accumulate=accumulate), _engine(accumulate=accumulate)
+    for step in range(2):
+        q, k, v = _inputs(2, heads, hw, seed=7 * step + head_dim, head_dim=head_dim)
+        out = fused.attend(0, q, k, v, heads, scale, 1, True, tapped=True)
+        assert out is not None and out.shape == q.shape
+        plain.tap_qk(0, q, k, heads, scale, 1, True)
+        want, _ = _restated_f64(q, k, v, heads, scale)
+        want_eager, _ = _reference_eager(q, k, v, heads, scale)
+        ref_scale = want.float().abs().max().item()
+        assert (out.float().cpu() - want.float()).abs().max().item() <= 2e-3 * ref_scale
+        assert (out.float() - want_eager.float()).abs().max().item() <= 2e-3 * ref_scale
+    a, b = dict(fused.items()), dict(plain.items())
+    assert list(a) == list(b)
+    for key in a:
+        if head_dim <= 64:
+            assert torch.equal(a[key], b[key]), key
+        else:
+            diff = (a[key].float() - b[key].float()).abs()
+            assert diff.max().item() <= 2.0 ** -6 * b[key].float().max().item() + 2e-3, key
+            assert (diff > 0).float().mean().item() <= 0.02, key
+    fused.close()
+    plain.close()
+
+
 def test_attend_unrounded_logits_and_general_scale():
     """``upcast_attention`` (logits stay f32) and a scale that is not a power of two take the exact-softmax variants."""
     q, k, v = _inputs(2, 4, 1024, seed=5)
@@ -133,7 +164,9 @@ def test_attend_declines_what_the_kernel_does_not_take():
     eng = _engine()
     q, k, v = _inputs(2, 4, 256, seed=1)
     assert eng.attend(0, q.float(), k.float(), v.float(), 4, 0.125, 1, True, tapped=False) is None        # fp32 pipeline
-    assert eng.attend(0, q[:, :, :128], k[:, :, :128], v[:, :, :128], 4, 32 ** -0.5, 1, True, tapped=False) is None  # head_dim 32
+    assert eng.attend(0, q[:, :, :48].contiguous(), k[:, :, :48].contiguous(), v[:, :, :48].contiguous(), 4, 12 ** -0.5, 1, True,
+                      tapped=False) is None                                                              # head_dim 12
+    assert eng.attend(0, q[:, :, :128], k[:, :, :128], v[:, :, :128], 4, 32 ** -0.5, 1, True, tapped=False) is None  # strided views
     assert eng.attend(0, q, k[:, :64], v[:, :64], 4, 0.125, 1, True, tapped=False) is None                # 64 keys
     assert eng.attend(0, q.transpose(0, 1).contiguous().transpose(0, 1), k, v, 4, 0.125, 1, True, tapped=False) is None
     assert eng.attend(0, q, k, v, 4, 0.125, 1, True, tapped=False) is not None
