@@ -23,7 +23,7 @@ int tap_mfma_tile_pixels();
 int tap_mfma_ksteps(int head_dim);
 int tap_mfma_max_steps();
 hipError_t launch_tap_d64(const TapLaunch&, int in_dtype, int acc_dtype, int fast_exp, int full64, hipStream_t, int*, int*);
-bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+bool tap_d64_supported(int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                        const void* q, const void* k);
 
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
@@ -528,7 +528,7 @@ static int mfma_kind(const DaamCtx* c, const DaamQKDesc& d, const void* q, const
 
 static bool use_d64(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
-    return !c->no_d64 && tap_d64_supported(d.head_dim, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h,
+    return !c->no_d64 && tap_d64_supported(d.head_dim, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h,
                                            d.k_stride_b, d.k_stride_h, q, k);
 }
 
@@ -537,7 +537,7 @@ static bool use_d64(const DaamCtx* c, const DaamQKDesc& d, const void* q, const 
 static bool use_d64_bf16(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
     return d.in_dtype == DAAM_BF16 && !c->no_d64 && c->fast_exp && d.round_logits && d.tokens == 77 && d.hw % 8 == 0 &&
-           tap_d64_supported(d.head_dim, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h, d.k_stride_b,
+           tap_d64_supported(d.head_dim, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h, d.k_stride_b,
                              d.k_stride_h, q, k);
 }
 

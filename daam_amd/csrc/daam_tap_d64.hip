@@ -12,21 +12,33 @@
 //   logits = fp16(f32(q.k) * scale) -> f32 softmax -> fp16(p) -> acc += p (accumulator dtype).
 //
 // Workgroup = 256 threads = 4 waves = 128 pixels of one (layer, kept head); wave w: pixels
-// [32w, 32w+32) = groups 0 / 1 of 16.  "Swapped" product S^T = K Q^T: A = K rows from LDS (lane:
-// token row l&15 of the 16-row tile, k = 8*(l>>4)..+7 of the 32-wide k-step), B = Q^T straight
-// from HBM (lane: pixel l&15, same k split) - each lane fetches 2 x 16 bytes per group and the four
-// lanes of a pixel cover one contiguous 64-byte half row per k-step.  C/D: lane holds pixel
-// l&15 and tokens 16*mt + 4*(l>>4) + r (mt = 0..4, r = 0..3) = 20 slots.
-// K of a step sits in LDS as [80 rows][128 B + 32 B pad] (pad 32: conflict-free ds_read_b128 for
-// this access pattern), double-buffered, register-staged one step ahead like the generic kernel.
+// [32w, 32w+32) = groups 0 / 1 of 16.  "Swapped" product S^T = K Q^T: A = K rows (lane: token row
+// l&15 of the 16-row tile, k = 8*(l>>4)..+7 of the 32-wide k-step), B = Q^T (lane: pixel l&15, same
+// k split).  C/D: lane holds pixel l&15 and tokens 16*mt + 4*(l>>4) + r (mt = 0..4, r = 0..3) = 20 slots.
+// Both operands reach the MFMAs through LDS in FULL 128-byte rows: K of a step as [80 rows][128 B],
+// double-buffered; Q of a step as a wave-private [32 pixel rows][128 B] tile.  Either is fetched from
+// HBM one step ahead into registers by coalesced loads (eight consecutive lanes = one whole row) and
+// written with its 16-byte chunks XOR-swizzled by (row >> 1) & 7, which makes the operand reads
+// (16 rows x one chunk per ds_read_b128) conflict-free without padding.  Round 2 fetched Q straight into
+// the MFMA layout (16 rows x 64 B per load instruction): the same bytes, but 16 bytes per L1 tag
+// lookup -- 0.67 lookups per cycle per CU and a read-tag-conflict stall in 20 % of the cycles
+// (TCP_TOTAL_CACHE_ACCESSES, TCP_READ_TAGCONFLICT_STALL_CYCLES; profiles/r02_tap_tcp.txt).
 #include "daam_tap16.h"
 
 namespace daam {
 
+constexpr int kTapRow = 128;                        // bytes per K / Q row in LDS (head_dim 64 x fp16), chunks swizzled
+constexpr int kTapKBuf = kD64Rows * kTapRow;        // 10240: 80 K rows, rows 77..79 stay zero
+constexpr int kTapQTile = 32 * kTapRow;             // 4096: one wave's 32 pixel rows
+constexpr int kTapQOff = 2 * kTapKBuf;              // Q tiles of the four waves follow the two K buffers
+
 template <typename ACC_T> constexpr size_t tap_d64_lds_bytes() {
-    const size_t kb = 2 * (size_t)kD64KBuf, st = (size_t)kTok * kMfmaPixels * sizeof(ACC_T);
-    return (kb > st ? kb : st) + (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);
+    const size_t kb = 2 * (size_t)kTapKBuf + 4 * (size_t)kTapQTile, st = (size_t)kTok * kMfmaPixels * sizeof(ACC_T);
+    return (kb > st ? kb : st) + (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);     // fp16 sums: 37888 -> 4 workgroups per CU
 }
+
+// byte offset of 16-byte chunk `chunk` inside row `row` of a swizzled [rows][128 B] image
+__device__ __forceinline__ constexpr int swz_chunk(int row, int chunk) { return ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // softmax over the 77 tokens of the lane's pixel (20 slots here, 57 in the three partner lanes)
 // + accumulate.  c[mt][r] = f32 q.k of token 16mt + 4h + r.
@@ -225,21 +237,17 @@ __device__ __forceinline__ void softmax20_accumulate(const floatx4 (&c)[5], cons
 
 // FULL64: every layer of the launch has head_dim == 64 (SDXL): the zero-padding selects of the head_dim < 64 case (8 VALU per
 // wave-step) are compiled out
-#ifndef DAAM_TAP_QDEPTH
-#define DAAM_TAP_QDEPTH 1          // steps the Q fetch runs ahead (2: a second register set, 3 waves per SIMD)
-#endif
 template <typename IN, typename ACC_T, bool FAST_EXP, bool FULL64>
-__global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16 && DAAM_TAP_QDEPTH == 1) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
+__global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
 {
-    constexpr int kQDepth = DAAM_TAP_QDEPTH;
     constexpr int KCH = (kTok * 8 + 255) / 256;               // 16-B K pieces per thread per step (3)
     constexpr int VEC = AccVec<ACC_T>::kPerVec;
     constexpr int PPR = kMfmaPixels / VEC;
     constexpr size_t kPtrOff = tap_d64_lds_bytes<ACC_T>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);
 
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* kbuf = smem;                               // [2][kD64KBuf]
-    ACC_T* stage = reinterpret_cast<ACC_T*>(smem);            // [kTok][kMfmaPixels], aliases kbuf
+    unsigned char* kbuf = smem;                               // [2][kTapKBuf], then the four waves' Q tiles
+    ACC_T* stage = reinterpret_cast<ACC_T*>(smem);            // [kTok][kMfmaPixels], aliases both
     const void** sptr = reinterpret_cast<const void**>(smem + kPtrOff);
 
     const int wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
@@ -303,96 +311,123 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16 && DAAM_TAP
     }
     __syncthreads();                                          // staging reads done; sptr visible
     // head_dim < 64 (multiple of 8; SD-v1.5's 40): the contraction runs over 64 with zeros beyond head_dim --
-    // K pieces past it are never written (the buffers are zeroed once), the lanes' Q pieces past it are
-    // fetched from a valid address and cleared before the MFMAs.
+    // K chunks past it are never written (the buffers are zeroed once), Q chunks past it are fetched from a valid
+    // address and cleared before they are written to LDS.
     const int d = lay.head_dim;
     const bool partial = !FULL64 && d < 64;                   // wave-uniform
     if (partial) {
-        for (int i = tid; i < 2 * kD64KBuf / 16; i += 256)
+        for (int i = tid; i < 2 * kTapKBuf / 16; i += 256)
             *reinterpret_cast<float4v*>(kbuf + i * 16) = float4v{0, 0, 0, 0};
+        __syncthreads();                                      // the first K tile lands on top of the zeros
     } else {
         // K rows 77..79 (never written by a step) must be finite: zero them once, both buffers
-        for (int i = tid; i < 2 * 3 * (kD64Row / 16); i += 256) {
-            const int buf = i / (3 * (kD64Row / 16)), r = i % (3 * (kD64Row / 16));
-            *reinterpret_cast<float4v*>(kbuf + buf * kD64KBuf + kTok * kD64Row + r * 16) = float4v{0, 0, 0, 0};
+        for (int i = tid; i < 2 * 3 * (kTapRow / 16); i += 256) {
+            const int buf = i / (3 * (kTapRow / 16)), r = i % (3 * (kTapRow / 16));
+            *reinterpret_cast<float4v*>(kbuf + buf * kTapKBuf + kTok * kTapRow + r * 16) = float4v{0, 0, 0, 0};
         }
     }
 
-    // per-thread K piece coordinates: piece c = tid + 256 j2 -> row c / 8, piece c % 8
-    int k_src[KCH], k_dst[KCH];
+    // per-thread K piece coordinates: piece c = tid + 256 j2 -> row t = c / 8 = (tid >> 3) + 32 j2, chunk c % 8.  The swizzle
+    // key ((t >> 1) & 7) and the validity of the chunk do not depend on j2, so ONE LDS offset (+ 4096 j2) and ONE global
+    // offset (+ 32 rows for piece 1, folded into the scalar base; piece 2 has its own, because the threads whose row would
+    // be 77..95 re-read their piece 0 instead) serve the three pieces.
+    static_assert(KCH == 3, "three K pieces per thread");
+    const int k_t = tid >> 3, k_ch = tid & 7;
+    const bool k_in_row = k_ch * 8 < d;                       // chunk inside the head's d elements
+    const bool k_row2 = k_t + 64 < kTok;                      // piece 2 exists
+    const unsigned k_src0 = (unsigned)((k_t * (int)lay.k_st + (k_in_row ? k_ch * 8 : 0)) * 2);
+    const int k_dst0 = k_t * kTapRow + swz_chunk(k_t, k_ch);
+    const unsigned k_step = (unsigned)__builtin_amdgcn_readfirstlane(32 * (int)lay.k_st * 2);   // bytes per 32 K rows
+    const unsigned k_src2 = k_row2 ? k_src0 + 2 * k_step : k_src0;
+    // Q pieces of this lane: piece p = lane + 64 i (i = 0..3) of the wave's 32 pixel rows -> row = p >> 3 = (lane >> 3) + 8 i,
+    // chunk = lane & 7.  Addresses = wave-uniform base (the step's tensor pointer, made an SGPR pair by readfirstlane; + 8 i
+    // pixel rows for piece i) + ONE 32-bit per-lane byte offset that never changes.  tap_d64_supported() keeps every
+    // offset below 2^31.
+    const int q_row = lane >> 3, q_chunk = lane & 7;
+    const bool q_valid = q_chunk * 8 < d;
+    const unsigned q_co = q_valid ? q_chunk * 16 : 0;
+    const int q_px = p0 + wave * 32 + q_row;
+    const unsigned q_b0 = (unsigned)((q_off + (int64_t)min(q_px, lay.hw - 1) * lay.q_sp) * 2) + q_co;
+    // piece i sits 8 i pixel rows further: a wave-uniform byte step added to the scalar base.  hw is a multiple of 8
+    // (tap_d64_supported), so a piece is inside the layer for all of its lanes or for none; a piece outside re-reads piece 0's
+    // rows (or, when the whole wave is outside, the layer's last row: q_b0 is clamped) and its results are never stored.
+    const int q_rows_in = __builtin_amdgcn_readfirstlane(lay.hw - (p0 + wave * 32));
+    const unsigned q_step8 = (unsigned)__builtin_amdgcn_readfirstlane(8 * (int)lay.q_sp * 2);   // bytes per 8 pixel rows
+    unsigned q_s[4];
 #pragma unroll
-    for (int j2 = 0; j2 < KCH; ++j2) {
-        const int c = tid + 256 * j2;
-        const int t = c >> 3, ch = c & 7;
-        const bool in_row = ch * 8 < d;                       // piece inside the head's d elements
-        k_src[j2] = min(t, kTok - 1) * (int)lay.k_st + (in_row ? ch * 8 : 0);
-        k_dst[j2] = (t < kTok && in_row) ? t * kD64Row + ch * 16 : -1;
-    }
-    const int px0 = min(p0 + wave * 32 + j, lay.hw - 1), px1 = min(p0 + wave * 32 + 16 + j, lay.hw - 1);
-    const bool qv0 = 8 * h < d, qv1 = 32 + 8 * h < d;         // this lane's piece of k-step 0 / 1 exists
-    const int qo0 = qv0 ? 8 * h : 0, qo1 = qv1 ? 32 + 8 * h : 0;
-    // Addresses = wave-uniform base (the step's tensor pointer, made an SGPR pair by readfirstlane) + a 32-bit per-lane BYTE
-    // offset that never changes: the loads take the scalar-base form and the loop has no 64-bit address arithmetic (10
-    // v_lshl_add_u64 per wave-step before) and 4 address registers fewer.  tap_d64_supported() keeps every offset below 2^31.
-    const unsigned q_b0 = (unsigned)((q_off + (int64_t)px0 * lay.q_sp) * 2), q_b1 = (unsigned)((q_off + (int64_t)px1 * lay.q_sp) * 2);
-    const unsigned q_o0 = (unsigned)qo0 * 2, q_o1 = (unsigned)qo1 * 2;
-    auto uniform = [](const void* p) -> const char* {
+    for (int i = 0; i < 4; ++i) q_s[i] = 8 * i < q_rows_in ? (unsigned)i * q_step8 : 0u;
+    // LDS write position of piece i: row (q_row + 8 i), swizzle key ((lane >> 4) + 4 i) & 7 = (lane >> 4) ^ 4 (i & 1)
+    unsigned char* qtile = kbuf + kTapQOff + wave * kTapQTile;
+    const int q_wr = q_row * kTapRow + ((q_chunk ^ (lane >> 4)) << 4);
+    // operand reads: row l&15 of a 16-row tile, chunk 4 ks + (l >> 4); the same offset serves K (A) and Q (B)
+    const int f_rd = j * kTapRow + swz_chunk(j, h);            // k-step 1: ^ 64
+    // Fetches are raw buffer loads: address = the step's tensor (a wave-uniform resource descriptor built from the pointer
+    // in SGPRs) + a per-lane 32-bit byte offset that never changes + a wave-uniform byte offset.  No 64-bit address
+    // arithmetic on the VALU (7 v_lshl_add_u64 per wave-step with plain global loads), offsets stay single registers.
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    auto tensor = [](const void* p) -> __amdgpu_buffer_rsrc_t {
         const unsigned long long v = reinterpret_cast<unsigned long long>(p);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, -1, 0x00020000);
     };
+    const unsigned k_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(k_off * 2));
 
     float4v kreg[KCH];
     auto issue_k = [&](int s) {
-        const char* kp = uniform(sptr[2 * s + 1]) + k_off * 2;
-#pragma unroll
-        for (int j2 = 0; j2 < KCH; ++j2) kreg[j2] = *as_global<float4v>(kp + (unsigned)k_src[j2] * 2u);
+        const __amdgpu_buffer_rsrc_t kt = tensor(sptr[2 * s + 1]);
+        kreg[0] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(kt, k_src0, k_base, 0));
+        kreg[1] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(kt, k_src0, k_base + k_step, 0));
+        kreg[2] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(kt, k_src2, k_base, 0));
     };
     auto commit_k = [&](int buf) {
+        unsigned char* kb = kbuf + buf * kTapKBuf + k_dst0;
+        if (k_in_row) {
+            *reinterpret_cast<float4v*>(kb) = kreg[0];
+            *reinterpret_cast<float4v*>(kb + 32 * kTapRow) = kreg[1];
+            if (k_row2) *reinterpret_cast<float4v*>(kb + 64 * kTapRow) = kreg[2];
+        }
+    };
+    float4v qreg[4];
+    auto issue_q = [&](int s) {
+        const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
 #pragma unroll
-        for (int j2 = 0; j2 < KCH; ++j2)
-            if (k_dst[j2] >= 0) *reinterpret_cast<float4v*>(kbuf + buf * kD64KBuf + k_dst[j2]) = kreg[j2];
+        for (int i = 0; i < 4; ++i) qreg[i] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(qt, q_b0, q_s[i], 0));
     };
-    // Q of one step: this lane's two 16-byte pieces for each of its two pixel groups
-    struct QRegs { half8 g0[2], g1[2]; };
-    auto issue_q = [&](int s, QRegs& q) {
-        const char* qp = uniform(sptr[2 * s]);
-        q.g0[0] = *as_global<half8>(qp + (q_b0 + q_o0));
-        q.g0[1] = *as_global<half8>(qp + (q_b0 + q_o1));
-        q.g1[0] = *as_global<half8>(qp + (q_b1 + q_o0));
-        q.g1[1] = *as_global<half8>(qp + (q_b1 + q_o1));
+    auto commit_q = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4v v = (partial && !q_valid) ? float4v{0, 0, 0, 0} : qreg[i];
+            *reinterpret_cast<float4v*>(qtile + i * 8 * kTapRow + (q_wr ^ (64 * (i & 1)))) = v;
+        }
     };
-    const unsigned char* a_rd = kbuf + j * kD64Row + h * 16;  // + buf * kD64KBuf + mt * 16 rows + ks * 64
 
-    // one denoising step: logits of step s from q (fetched kQDepth steps ago) and the K tile in LDS, then the fetches of later
-    // steps (K: step s + 1 into registers; Q: step s + kQDepth into the registers this step just freed), softmax + accumulate
-    // of the two pixel groups, K of step s + 1 into the other LDS buffer
-    auto step = [&](int s, QRegs& q) {
+    // one denoising step: logits of step s from the K and Q tiles in LDS, then the fetches of step s + 1 into registers,
+    // softmax + accumulate of the two pixel groups, K and Q of step s + 1 into LDS (K: the other buffer; Q: this wave's
+    // own tile, whose reads are behind it)
+    auto step = [&](int s) {
 #if !defined(DAAM_TAP_ABLATE) || DAAM_TAP_ABLATE != 1         // timing experiment 1: no per-step barrier (results are wrong)
         __syncthreads();
 #endif
-        const unsigned char* kb = a_rd + (s & 1) * kD64KBuf;
-        if (partial) {
-            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (!qv0) { q.g0[0] = z; q.g1[0] = z; }
-            if (!qv1) { q.g0[1] = z; q.g1[1] = z; }
-        }
+        const unsigned char* kb = kbuf + (s & 1) * kTapKBuf;
+        const half8 q00 = *reinterpret_cast<const half8*>(qtile + f_rd), q01 = *reinterpret_cast<const half8*>(qtile + (f_rd ^ 64));
+        const half8 q10 = *reinterpret_cast<const half8*>(qtile + 16 * kTapRow + f_rd);
+        const half8 q11 = *reinterpret_cast<const half8*>(qtile + 16 * kTapRow + (f_rd ^ 64));
         floatx4 c0[5], c1[5];
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
-            const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kD64Row);
-            const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kD64Row + 64);
-            c0[mt] = IN::mfma(a0, q.g0[0], floatx4{0, 0, 0, 0});
-            c1[mt] = IN::mfma(a0, q.g1[0], floatx4{0, 0, 0, 0});
-            c0[mt] = IN::mfma(a1, q.g0[1], c0[mt]);
-            c1[mt] = IN::mfma(a1, q.g1[1], c1[mt]);
+            const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kTapRow + f_rd);
+            const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kTapRow + (f_rd ^ 64));
+            c0[mt] = IN::mfma(a0, q00, floatx4{0, 0, 0, 0});
+            c1[mt] = IN::mfma(a0, q10, floatx4{0, 0, 0, 0});
+            c0[mt] = IN::mfma(a1, q01, c0[mt]);
+            c1[mt] = IN::mfma(a1, q11, c1[mt]);
         }
 #if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 2           // timing experiment 2: every step re-reads step 0 (cache-resident)
         issue_k(0);
-        issue_q(0, q);
+        issue_q(0);
 #else
-        issue_k(min(s + 1, n_steps - 1));                     // branch-free: the last steps re-fetch the last one
-        issue_q(min(s + kQDepth, n_steps - 1), q);
+        issue_k(min(s + 1, n_steps - 1));                     // branch-free: the last step re-fetches itself
+        issue_q(min(s + 1, n_steps - 1));
 #endif
         if constexpr (IN::kBf16) {
             softmax20_accumulate_bf16<ACC_T>(c0, lay, h, run0);
@@ -402,24 +437,13 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16 && DAAM_TAP
             softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
         }
         commit_k((s + 1) & 1);
+        commit_q();
     };
-    QRegs qa;
     issue_k(0);
-    issue_q(0, qa);
+    issue_q(0);
     commit_k(0);
-    if constexpr (kQDepth == 1) {
-        for (int s = 0; s < n_steps; ++s) step(s, qa);
-    } else {
-        // Q two steps ahead in two register sets that alternate (static names: the loop is unrolled by two)
-        QRegs qb;
-        issue_q(min(1, n_steps - 1), qb);
-        int s = 0;
-        for (; s + 1 < n_steps; s += 2) {
-            step(s, qa);
-            step(s + 1, qb);
-        }
-        if (s < n_steps) step(s, qa);
-    }
+    commit_q();
+    for (int s = 0; s < n_steps; ++s) step(s);
     __syncthreads();                                          // all K reads done before the staging tile reuses the space
 
     // ---- write back: registers -> LDS [token][pixel] -> 16-byte row pieces -------------------
@@ -440,10 +464,10 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16 && DAAM_TAP
     }
 }
 
-bool tap_d64_supported(int head_dim, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+bool tap_d64_supported(int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                        const void* q, const void* k)
 {
-    if (head_dim < 8 || head_dim > 64 || head_dim % 8 != 0) return false;
+    if (head_dim < 8 || head_dim > 64 || head_dim % 8 != 0 || hw % 8 != 0) return false;
     const int64_t s[] = {q_sp, k_st, q_sb, q_sh, k_sb, k_sh};
     for (int64_t v : s)
         if (v % 8 != 0) return false;
