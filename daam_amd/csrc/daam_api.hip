@@ -584,7 +584,8 @@ int daam_attend_supported(const DaamAttendDesc* d, const void* q, const void* k,
                                d->qk.k_stride_t, d->v_stride_b, d->v_stride_h, d->v_stride_t, d->o_stride_b, d->o_stride_h,
                                d->o_stride_p};
     const void* ptrs[] = {q, k, v, out};
-    if (d->qk.batch <= 0 || d->qk.heads <= 0 || d->qk.hw <= 0) return 0;
+    // hw % 8: the fused tap updates the running sums in 16-byte row pieces (8 fp16 pixels), rows must start aligned
+    if (d->qk.batch <= 0 || d->qk.heads <= 0 || d->qk.hw <= 0 || d->qk.hw % 8 != 0) return 0;
     return attend_d64_supported(d->qk.in_dtype, d->qk.head_dim, d->qk.tokens, strides, 12, ptrs, 4) ? 1 : 0;
 }
 
@@ -593,7 +594,7 @@ int daam_attend(DaamCtx* c, int layer, const void* q, const void* k, const void*
 {
     if (!c || !d || !q || !k || !v || !out) return fail(DAAM_E_INVALID, "NULL argument");
     if (!daam_attend_supported(d, q, k, v, out))
-        return fail(DAAM_E_UNSUPPORTED, "daam_attend: fp16, head_dim %% 8 == 0 up to 160, 77 tokens, strides %% 8 == 0, 16-byte aligned pointers only");
+        return fail(DAAM_E_UNSUPPORTED, "daam_attend: fp16, head_dim %% 8 == 0 up to 160, 77 tokens, hw %% 8 == 0, strides %% 8 == 0, 16-byte aligned pointers only");
     if (d->qk.tokens != c->tokens) return fail(DAAM_E_INVALID, "tokens %d != context size %d", d->qk.tokens, c->tokens);
     if (tap) {
         int rc = check_qk(c, layer, q, k, &d->qk);

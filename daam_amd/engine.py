@@ -371,7 +371,8 @@ class HeatMapEngine:
                 or a[4] != scale or a[5] != round_logits):
             a = self._prepare_attend(layer, query, key, value, heads, scale, round_logits)
         if (a[6] is None or value.shape != a[1] or key.dtype is not a[2] or value.dtype is not a[2]
-                or not (query.is_contiguous() and key.is_contiguous() and value.is_contiguous())):
+                or not (query.is_contiguous() and key.is_contiguous() and value.is_contiguous())
+                or (query.requires_grad and torch.is_grad_enabled())):     # the kernel has no backward: leave autograd to torch
             return None
         fused_tap = tapped and not self.defer_steps
         if fused_tap:
@@ -402,7 +403,7 @@ class HeatMapEngine:
         d = query.shape[2] // heads if query.dim() == 3 and heads > 0 else 0
         if (query.dtype is torch.float16 and query.dim() == 3 and key.dim() == 3 and key.shape[1] == self.tokens
                 and d * heads == query.shape[2] and key.shape[2] == query.shape[2] and query.shape[0] == key.shape[0]
-                and d % 8 == 0 and 8 <= d <= 160):
+                and d % 8 == 0 and 8 <= d <= 160 and query.shape[1] % 8 == 0):
             self._ensure_ctx(query.dtype)
             if self.acc_dtype in (torch.float16, torch.float32):
                 b, hw, c = query.shape

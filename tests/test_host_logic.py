@@ -329,6 +329,55 @@ def test_cxx_recorder_releases_storages_on_its_thread(fake_engine):
     eng.close()
 
 
+def test_engine_attend_bookkeeping(fake_engine):
+    """``HeatMapEngine.attend`` against the recording fake of libdaam_hip: which calls take the kernel, what the
+    descriptor says, fused tap on an immediate trace vs recorded tap on a deferred one."""
+    import ctypes
+    E, lib = fake_engine
+    q = torch.zeros(2, 64, 4 * 40, dtype=torch.float16)                    # 4 heads of 40 (SD-v1.5's 64x64 layers)
+    k, v = torch.zeros(2, 77, 160, dtype=torch.float16), torch.zeros(2, 77, 160, dtype=torch.float16)
+    # deferred trace: the kernel attends (tap = 0) and the call is recorded for the batched launch
+    eng = E.HeatMapEngine(2, defer_steps=4)
+    out = eng.attend(1, q, k, v, 4, 40 ** -0.5, 1, True, tapped=True)
+    assert out is not None and out.shape == q.shape and out.dtype == q.dtype
+    name, args = lib.calls[-1] if lib.calls[-1][0] == 'daam_attend' else [c for c in lib.calls if c[0] == 'daam_attend'][-1]
+    assert args[1] == 1 and args[7] == 0
+    assert args[2:6] == (q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr())
+    desc = ctypes.cast(args[6], ctypes.POINTER(E.nat.AttendDesc)).contents if not hasattr(args[6], '_obj') else args[6]._obj
+    assert (desc.qk.batch, desc.qk.heads, desc.qk.hw, desc.qk.tokens, desc.qk.head_dim) == (2, 4, 64, 77, 40)
+    assert (desc.qk.q_stride_b, desc.qk.q_stride_h, desc.qk.q_stride_p) == (64 * 160, 40, 160)
+    assert (desc.v_stride_b, desc.v_stride_h, desc.v_stride_t) == (77 * 160, 40, 160)
+    assert (desc.o_stride_b, desc.o_stride_h, desc.o_stride_p) == (64 * 160, 40, 160)
+    assert eng.pending_taps == 1 and eng.touched == [1] and 'daam_tap_qk' not in lib.names()
+    # an un-tapped call (reference gate, trace.py:289) attends only
+    eng.attend(0, q, k, v, 4, 40 ** -0.5, 8, True, tapped=False)
+    assert eng.pending_taps == 1 and eng.touched == [1]
+    # immediate trace: the tap is fused into the kernel (tap = 1), nothing is recorded, no stand-alone tap is launched
+    imm = E.HeatMapEngine(2, defer_steps=0)
+    n_before = len(lib.calls)
+    out = imm.attend(0, q, k, v, 4, 40 ** -0.5, 1, True, tapped=True)
+    new = [c for c in lib.calls[n_before:]]
+    assert [c[0] for c in new if c[0] in ('daam_attend', 'daam_tap_qk', 'daam_layer_configure')] == ['daam_layer_configure', 'daam_attend']
+    assert new[-1][1][7] == 1 and imm.pending_taps == 0 and imm.touched == [0]
+    assert imm.layer_info[0] == (1, 4, 8)                                   # (factor, kept heads, side)
+    # calls the kernel does not take: fp32 pipeline, head_dim not a multiple of 8, not 77 keys, strided input, autograd
+    n_before = len(lib.calls)
+    assert imm.attend(1, q.float(), k.float(), v.float(), 4, 40 ** -0.5, 1, True, tapped=True) is None
+    assert imm.attend(1, q[:, :, :48].contiguous(), k[:, :, :48].contiguous(), v[:, :, :48].contiguous(), 4, 12 ** -0.5, 1) is None
+    assert imm.attend(1, q, k[:, :64].contiguous(), v[:, :64].contiguous(), 4, 40 ** -0.5, 1) is None
+    assert imm.attend(1, q.transpose(0, 1).contiguous().transpose(0, 1), k, v, 4, 40 ** -0.5, 1) is None
+    qg = q.clone().requires_grad_(True)
+    assert imm.attend(1, qg, k, v, 4, 40 ** -0.5, 1) is None
+    with torch.no_grad():
+        assert imm.attend(1, qg, k, v, 4, 40 ** -0.5, 1) is not None
+    assert [c[0] for c in lib.calls[n_before:]].count('daam_attend') == 1
+    # a library that declines (unaligned view) makes the caller fall back instead of failing
+    lib.__dict__['daam_attend'] = lambda *a: E.nat.E_UNSUPPORTED
+    assert imm.attend(0, q, k, v, 4, 40 ** -0.5, 1, True, tapped=True) is None
+    eng.close()
+    imm.close()
+
+
 @pytest.mark.parametrize('recorder', ['c++', 'python'])
 def test_defer_byte_budget(fake_engine, monkeypatch, recorder):
     """The recorded Q / K are kept alive until their launch: a byte budget forces the launch early."""
