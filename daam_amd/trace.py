@@ -3,10 +3,11 @@ over the MI355X-native extraction path.
 
 Differences from the reference are confined to *how* the per-layer work is done:
   * the cross-attention processor does not materialise ``attention_probs`` on the default
-    path: the model's output comes from fused SDPA, and the heat-map tap recomputes the
-    conditional-half probabilities from the projected Q / K inside one HIP kernel
-    (``daam_tap_qk``), optionally deferred so that several denoising steps of all layers
-    run as a single launch;
+    path: the attention itself runs on ``daam_attend`` (softmax(QK^T)V with the reference's
+    rounding points, one MFMA kernel; the framework's fused SDPA where that kernel does not
+    apply), and the heat-map tap either happens inside the same kernel (``defer_steps=0``) or
+    recomputes the conditional-half probabilities from the projected Q / K in ONE launch for
+    several denoising steps of all layers (``daam_tap_qk_enqueue`` / ``daam_tap_flush``, the default);
   * ``compute_global_heat_map`` is one fused bicubic + clamp + mean kernel.
 The materialised path (``get_attention_scores`` -> ``daam_tap_probs`` -> ``bmm``) is kept for
 ``save_heads`` / ``load_heads``, attention masks, and ``tap='probs'``.
@@ -211,8 +212,9 @@ class UNetCrossAttentionHooker(ObjectHooker):
     """The attention processor installed on every located ``attn2`` (diffusers attention-processor protocol;
     replaces the reference's processor, trace.py:252-311).
 
-    Default route: the model's output comes from fused SDPA and the heat-map tap gets the projected Q / K
-    (``HeatMapEngine.tap_qk`` -- nothing ``[BH, hw, 77]``-sized is ever materialised).  Materialised route
+    Default route: the model's output comes from ``HeatMapEngine.attend`` (``daam_attend``; the framework's fused SDPA
+    for calls that kernel does not take) and the heat-map tap gets the projected Q / K (fused into the same kernel on
+    an immediate trace, ``HeatMapEngine.tap_qk`` otherwise -- nothing ``[BH, hw, 77]``-sized is ever materialised).  Materialised route
     (``get_attention_scores`` -> ``tap_probs`` -> ``bmm``) for attention masks, ``upcast_softmax``,
     ``save_heads`` / ``load_heads`` and ``tap='probs'``."""
 
