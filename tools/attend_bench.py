@@ -1,7 +1,7 @@
 """daam_attend on the SDXL-1024 layer set: the kernel with and without the fused tap, next to the attention the stock
 processor runs (torch's fused SDPA) and to the stand-alone immediate tap.
 
-    python tools/attend_bench.py [denoise steps] [reps]            # one JSON line
+    python tools/attend_bench.py [denoise steps] [reps] [attend|attend_fused_tap]     # one JSON line
     rocprofv3 --kernel-trace --stats ... -- python tools/attend_bench.py 10 2   # per-kernel durations of the same loops
 
 Every loop issues, per denoising step, one call per hooked layer (60 for SDXL) on device-resident Q / K / V; times are
@@ -20,7 +20,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def measure(steps=50, reps=5, dev=None):
+def measure(steps=50, reps=5, dev=None, only=None):
     import bench
     from daam_amd.engine import HeatMapEngine
     dev = torch.device('cuda:0') if dev is None else dev
@@ -76,6 +76,10 @@ def measure(steps=50, reps=5, dev=None):
         plain.tap_qk(*a)
 
     res = dict(steps=steps, reps=reps, layers=len(layers))
+    if only:                                             # one loop only (PMC passes: one kind of launch per kernel name)
+        fn, prep = dict(attend=(attend_only, None), attend_fused_tap=(attend_tap, fused.clear))[only]
+        res[only] = best(fn, prepare=prep)
+        return res
     res['torch_sdpa'] = best(sdpa)
     res['attend'] = best(attend_only)
     res['attend_fused_tap'] = best(attend_tap, prepare=fused.clear)
@@ -98,7 +102,8 @@ def measure(steps=50, reps=5, dev=None):
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    print(json.dumps(measure(steps, reps)))
+    only = sys.argv[3] if len(sys.argv) > 3 else None
+    print(json.dumps(measure(steps, reps, only=only)))
 
 
 if __name__ == '__main__':
