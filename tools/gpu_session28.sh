@@ -4,6 +4,9 @@
 # kernel trace + FETCH_SIZE / WRITE_SIZE of the attend kernel with and without the fused tap
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 O=gpurun_out/s28; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1
+echo "pytest rc=$?" >> $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 bash tools/profile_round.sh r02 sdxl1024 50 50 30 5 > $O/prof_sdxl1024.log 2>&1
 bash tools/profile_round.sh r02 sd15 50 50 30 5 > $O/prof_sd15.log 2>&1
 bash tools/profile_round.sh r02 sdxl2048 100 24 4 2 > $O/prof_sdxl2048.log 2>&1
@@ -40,7 +43,7 @@ out['method'] = 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separat
 print(json.dumps(out, indent=1))
 PY
 rm -rf $O/prof_attend $O/pmc_*_FETCH_SIZE $O/pmc_*_WRITE_SIZE
-cat $O/bench_wall.txt
+grep -E "passed|failed|FAILED|rc=" $O/pytest.log | tail -4; tail -1 $O/smoke.log; cat $O/bench_wall.txt
 python -c "
 import json
 for n in ('bench_sdxl1024','bench_sdxl1024_run2','bench_sdxl1024_run3','bench_sd15','bench_sdxl2048'):
