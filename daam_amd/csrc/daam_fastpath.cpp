@@ -49,8 +49,15 @@ public:
         if (!usable()) { batch.clear(); return; }                 // synchronous: after shutdown(), in a forked child
         std::unique_lock<std::mutex> lock(mu_);
         if (!started_) {
-            started_ = true;
-            pid_thread_ = std::thread([this] { run(); });
+            try {
+                pid_thread_ = std::thread([this] { run(); });
+                started_ = true;
+            } catch (...) {                                       // no thread to be had: free inline from now on
+                off_.store(true);
+                lock.unlock();
+                batch.clear();
+                return;
+            }
         }
         idle_.wait(lock, [this] { return queue_.empty(); });
         queue_.push_back(std::move(batch));
