@@ -1,0 +1,3 @@
+#!/bin/bash
+R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
+bash tools/power_trace.sh gpurun_out/s29
