@@ -23,6 +23,9 @@ int tap_mfma_tile_pixels();
 int tap_mfma_ksteps(int head_dim);
 int tap_mfma_max_steps();
 hipError_t launch_tap_d64(const TapLaunch&, int in_dtype, int acc_dtype, int fast_exp, int full64, hipStream_t, int*, int*);
+bool tap_wide_supported(int in_dtype, int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+                        const void* q, const void* k);
+hipError_t launch_tap_wide(const TapLaunch&, int acc_dtype, int max_head_dim, int fast_exp, hipStream_t, int*, int*);
 bool tap_d64_supported(int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                        const void* q, const void* k);
 
@@ -541,10 +544,20 @@ static bool use_d64_bf16(const DaamCtx* c, const DaamQKDesc& d, const void* q, c
                              d.k_stride_h, q, k);
 }
 
+// 64 < head_dim <= 160 on fp16 pipelines (SD-v1.5's 80 / 160): the 16x16-tile kernel with 3 or 5 k-steps (daam_tap_wide.hip)
+static bool use_wide(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
+{
+    return !c->no_d64 && (c->acc_dtype == DAAM_F16 || c->acc_dtype == DAAM_F32) &&
+           (int64_t)d.batch * d.q_stride_b < ((int64_t)1 << 30) &&
+           tap_wide_supported(d.in_dtype, d.head_dim, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h, d.k_stride_b,
+                              d.k_stride_h, q, k);
+}
+
 static int mfma_kind(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
     if (d.in_dtype == DAAM_BF16) return 66;                   // only reached when use_d64_bf16() holds
     if (use_d64(c, d, q, k)) return 65;
+    if (use_wide(c, d, q, k)) return d.head_dim <= 96 ? 67 : 69;
     return tap_mfma_ksteps(d.head_dim);
 }
 
@@ -568,6 +581,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     c->last_block[0] = 256;
     const int kd1 = mfma ? mfma_kind(c, *d, q, k) : 0;
     hipError_t e = (kd1 == 65 || kd1 == 66) ? launch_tap_d64(L, d->in_dtype, c->acc_dtype, c->fast_exp && d->round_logits, d->head_dim == 64, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+                   : (kd1 == 67 || kd1 == 69) ? launch_tap_wide(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                         : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
                                              &c->last_grid[0], &c->last_lds[0]);
@@ -817,6 +831,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         }
         int grid = 0;
         hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, ks, &grid, &c->last_lds[0])
+                     : (pr.kd == 67 || pr.kd == 69) ? launch_tap_wide(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
                      : pr.kd ? launch_tap_mfma(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
                              : launch_tap_generic(pr.L, in_dtype, c->acc_dtype, pr.max_d, ks, &grid, &c->last_lds[0]);
         grid_total += grid;

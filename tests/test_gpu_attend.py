@@ -122,8 +122,8 @@ def test_fused_tap_leaves_the_sums_of_the_stand_alone_tap(batch, heads, hw, accu
 @pytest.mark.parametrize('head_dim,hw', [(40, 4096), (80, 1024), (160, 256), (8, 64), (96, 576), (128, 256)])
 def test_attend_other_head_dims(head_dim, hw, accumulate):
     """SD-v1.5's head dims (40 / 80 / 160, 8 heads) and the corners of the three kernel shapes: output against the float64
-    restatement and the reference ops, fused tap against the stand-alone tap (bit-identical where both run the 16x16x32
-    tiling, i.e. head_dim <= 64; to fp16-flip accuracy where the stand-alone tap is the 32x32x16 kernel)."""
+    restatement and the reference ops, fused tap against the stand-alone tap (bit-identical: daam_tap_d64 / daam_tap_wide and
+    daam_attend share the 16x16x32 tiling and the softmax code)."""
     heads, scale = 8, head_dim ** -0.5
     fused, plain = _engine(accumulate=accumulate), _engine(accumulate=accumulate)
     for step in range(2):
@@ -139,12 +139,7 @@ def test_attend_other_head_dims(head_dim, hw, accumulate):
     a, b = dict(fused.items()), dict(plain.items())
     assert list(a) == list(b)
     for key in a:
-        if head_dim <= 64:
-            assert torch.equal(a[key], b[key]), key
-        else:
-            diff = (a[key].float() - b[key].float()).abs()
-            assert diff.max().item() <= 2.0 ** -6 * b[key].float().max().item() + 2e-3, key
-            assert (diff > 0).float().mean().item() <= 0.02, key
+        assert torch.equal(a[key], b[key]), key                  # same tiling, same MFMA order, same softmax code
     fused.close()
     plain.close()
 
