@@ -54,11 +54,14 @@ def build_fastpath(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
         return out
     lib_dirs = ext.library_paths()
-    cmd = ['g++', '-O2', '-std=c++17', '-fPIC', '-shared',
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    # host code only; the HIP platform define and headers are for c10::hip::getCurrentHIPStream (the recorder launches
+    # daam_attend on torch's current stream), nothing here is compiled for the device
+    cmd = ['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-D__HIP_PLATFORM_AMD__', '-DUSE_ROCM',
            f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}',
-           '-I' + sysconfig.get_paths()['include'], *['-I' + p for p in ext.include_paths()],
+           '-I' + sysconfig.get_paths()['include'], *['-I' + p for p in ext.include_paths()], '-I' + os.path.join(rocm, 'include'),
            src, '-o', out, *['-L' + p for p in lib_dirs], *['-Wl,-rpath,' + p for p in lib_dirs],
-           '-ltorch_python', '-ltorch', '-ltorch_cpu', '-lc10']
+           '-ltorch_python', '-ltorch', '-ltorch_cpu', '-lc10', '-lc10_hip']
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -19,7 +19,10 @@
 #include <torch/csrc/autograd/python_variable.h>
 #include <ATen/core/Tensor.h>
 
+#include <ATen/Functions.h>
+#include <c10/core/GradMode.h>
 #include <c10/core/Storage.h>
+#include <c10/hip/HIPStream.h>
 
 #include <pthread.h>
 
@@ -131,9 +134,28 @@ struct LayerCache {
     uint64_t desc = 0;           // address of the layer's DaamQKDesc (owned by the engine)
 };
 
+// daam_attend (include/daam_hip.h), reached through the address the engine takes from the loaded library
+using AttendFn = int (*)(void* ctx, int layer, const void* q, const void* k, const void* v, void* out, const void* desc, int tap,
+                         void* stream);
+
+struct AttendCache {             // a layer's validated attend() call: shapes, dtype, device, parameters, its DaamAttendDesc
+    bool valid = false;
+    int64_t q_size[3] = {0, 0, 0};
+    int64_t k_size[3] = {0, 0, 0};
+    int dtype = -1, device_type = -1, device = -1;
+    long heads = 0;
+    int round_logits = 1;
+    double scale = 0.0;
+    uint64_t desc = 0;
+};
+
 struct Recorder {
     PyObject_HEAD
     std::vector<LayerCache>* cache;
+    std::vector<AttendCache>* acache;
+    void* native_ctx;                   // DaamCtx* of the engine (0: none yet)
+    AttendFn attend_fn;                 // daam_attend, or null: every attend() goes to Python
+    PyObject* attend_slow_cb;           // engine._attend_slow(layer, q, k, v, heads, scale, factor, round_logits, tapped)
     std::vector<int32_t>* cnt;          // recorded steps per layer
     std::vector<uint8_t>* touched;      // engine._touch(layer) already called since clear()
     std::vector<int32_t>* layers;       // parallel arrays handed to daam_tap_qk_enqueue_many
@@ -156,6 +178,10 @@ int Recorder_init(Recorder* self, PyObject* args, PyObject* kw) {
     if (!PyArg_ParseTupleAndKeywords(args, kw, "iOOO", const_cast<char**>(names), &n, &slow, &flush, &touch)) return -1;
     if (n < 0) { PyErr_SetString(PyExc_ValueError, "n_layers < 0"); return -1; }
     self->cache = new std::vector<LayerCache>(n);
+    self->acache = new std::vector<AttendCache>(n);
+    self->native_ctx = nullptr;
+    self->attend_fn = nullptr;
+    self->attend_slow_cb = nullptr;
     self->cnt = new std::vector<int32_t>(n, 0);
     self->touched = new std::vector<uint8_t>(n, 0);
     self->layers = new std::vector<int32_t>();
@@ -172,20 +198,20 @@ int Recorder_init(Recorder* self, PyObject* args, PyObject* kw) {
 }
 
 int Recorder_traverse(Recorder* self, visitproc visit, void* arg) {
-    Py_VISIT(self->slow_cb); Py_VISIT(self->flush_cb); Py_VISIT(self->touch_cb);
+    Py_VISIT(self->slow_cb); Py_VISIT(self->flush_cb); Py_VISIT(self->touch_cb); Py_VISIT(self->attend_slow_cb);
     return 0;
 }
 
 int Recorder_clear(Recorder* self) {
-    Py_CLEAR(self->slow_cb); Py_CLEAR(self->flush_cb); Py_CLEAR(self->touch_cb);
+    Py_CLEAR(self->slow_cb); Py_CLEAR(self->flush_cb); Py_CLEAR(self->touch_cb); Py_CLEAR(self->attend_slow_cb);
     return 0;
 }
 
 void Recorder_dealloc(Recorder* self) {
     PyObject_GC_UnTrack(self);
-    delete self->cache; delete self->cnt; delete self->touched; delete self->layers;
+    delete self->cache; delete self->acache; delete self->cnt; delete self->touched; delete self->layers;
     delete self->qp; delete self->kp; delete self->dp; delete self->keep;
-    Py_XDECREF(self->slow_cb); Py_XDECREF(self->flush_cb); Py_XDECREF(self->touch_cb);
+    Py_XDECREF(self->slow_cb); Py_XDECREF(self->flush_cb); Py_XDECREF(self->touch_cb); Py_XDECREF(self->attend_slow_cb);
     Py_TYPE(self)->tp_free(reinterpret_cast<PyObject*>(self));
 }
 
@@ -219,6 +245,47 @@ inline void push(Recorder* self, int layer, const at::Tensor& q, const at::Tenso
     (*self->cnt)[layer] += 1;
 }
 
+// The steady state of a deferred tap: the call looks like the one the layer's descriptor was built for -> record it.
+// Returns 1: recorded; 0: not the steady state (the caller hands the call to Python); -1: a Python error is set.
+int record_steady(Recorder* self, long layer, PyObject* layer_obj, PyObject* qo, PyObject* ko, long heads, double scale, long factor,
+                  int rl) {
+    // torch accessors can throw (tensors without storage: fake / meta tensors under tracing); anything
+    // unusual goes to the Python path, which reports it properly
+    bool steady = false;
+    try {
+        const LayerCache& c = (*self->cache)[layer];
+        const at::Tensor& q = THPVariable_Unpack(qo);
+        const at::Tensor& k = THPVariable_Unpack(ko);
+        steady = c.valid && same3(q, c.q_size) && same3(k, c.k_size) &&
+                 static_cast<int>(q.scalar_type()) == c.dtype && static_cast<int>(k.scalar_type()) == c.dtype &&
+                 same_device(q, c) && same_device(k, c) &&
+                 heads == c.heads && factor == c.factor && scale == c.scale && rl == c.round_logits &&
+                 q.is_contiguous() && k.is_contiguous() && q.has_storage() && k.has_storage();
+    } catch (...) {
+        steady = false;
+    }
+    if (!steady) return 0;
+    if (!self->flush_cb || !self->touch_cb) { PyErr_SetString(PyExc_RuntimeError, "recorder is closed"); return -1; }
+    if (must_launch(self, layer)) {
+        PyObject* r = PyObject_CallNoArgs(self->flush_cb);     // launches, then calls drop()
+        if (!r) return -1;
+        Py_DECREF(r);
+    }
+    try {
+        push(self, static_cast<int>(layer), THPVariable_Unpack(qo), THPVariable_Unpack(ko), (*self->cache)[layer].desc);
+    } catch (const std::exception& e) {
+        PyErr_SetString(PyExc_RuntimeError, e.what());
+        return -1;
+    }
+    if (!(*self->touched)[layer]) {
+        PyObject* r = PyObject_CallOneArg(self->touch_cb, layer_obj);
+        if (!r) return -1;
+        Py_DECREF(r);
+        (*self->touched)[layer] = 1;
+    }
+    return 1;
+}
+
 // tap(layer, query, key, heads, scale, factor, round_logits=True) -> None
 PyObject* Recorder_tap(Recorder* self, PyObject* const* args, Py_ssize_t nargs, PyObject* kwnames) {
     const bool has_kw = kwnames != nullptr && PyTuple_GET_SIZE(kwnames) > 0;
@@ -231,47 +298,113 @@ PyObject* Recorder_tap(Recorder* self, PyObject* const* args, Py_ssize_t nargs, 
         if (PyErr_Occurred()) {
             PyErr_Clear();                                   // odd argument types: let Python complain
         } else if (layer >= 0 && layer < static_cast<long>(self->cache->size())) {
-            // torch accessors can throw (tensors without storage: fake / meta tensors under tracing); anything
-            // unusual goes to the Python path, which reports it properly
-            bool steady = false;
-            try {
-                const LayerCache& c = (*self->cache)[layer];
-                const at::Tensor& q = THPVariable_Unpack(args[1]);
-                const at::Tensor& k = THPVariable_Unpack(args[2]);
-                steady = c.valid && same3(q, c.q_size) && same3(k, c.k_size) &&
-                         static_cast<int>(q.scalar_type()) == c.dtype && static_cast<int>(k.scalar_type()) == c.dtype &&
-                         same_device(q, c) && same_device(k, c) &&
-                         heads == c.heads && factor == c.factor && scale == c.scale && rl == c.round_logits &&
-                         q.is_contiguous() && k.is_contiguous() && q.has_storage() && k.has_storage();
-            } catch (...) {
-                steady = false;
-            }
-            if (steady) {
-                if (!self->flush_cb || !self->touch_cb) { PyErr_SetString(PyExc_RuntimeError, "recorder is closed"); return nullptr; }
-                if (must_launch(self, layer)) {
-                    PyObject* r = PyObject_CallNoArgs(self->flush_cb);     // launches, then calls drop()
-                    if (!r) return nullptr;
-                    Py_DECREF(r);
-                }
-                try {
-                    push(self, static_cast<int>(layer), THPVariable_Unpack(args[1]), THPVariable_Unpack(args[2]),
-                         (*self->cache)[layer].desc);
-                } catch (const std::exception& e) {
-                    PyErr_SetString(PyExc_RuntimeError, e.what());
-                    return nullptr;
-                }
-                if (!(*self->touched)[layer]) {
-                    PyObject* r = PyObject_CallOneArg(self->touch_cb, args[0]);
-                    if (!r) return nullptr;
-                    Py_DECREF(r);
-                    (*self->touched)[layer] = 1;
-                }
-                Py_RETURN_NONE;
-            }
+            const int st = record_steady(self, layer, args[0], args[1], args[2], heads, scale, factor, rl);
+            if (st < 0) return nullptr;
+            if (st > 0) Py_RETURN_NONE;
         }
     }
     if (!self->slow_cb) { PyErr_SetString(PyExc_RuntimeError, "recorder is closed"); return nullptr; }
     return PyObject_Vectorcall(self->slow_cb, args, nargs, kwnames);
+}
+
+// attend(layer, query, key, value, heads, scale, factor, round_logits, tapped) -> Tensor | None
+// The processor's attention on daam_attend for a deferred trace: in the steady state (the call looks like the one the layer's
+// DaamAttendDesc was built for) allocate the output, launch on torch's current stream, record Q / K for the batched tap --
+// one C call instead of HeatMapEngine.attend's Python + ctypes (8 us -> the launch cost).  Everything else goes to the engine.
+PyObject* Recorder_attend(Recorder* self, PyObject* const* args, Py_ssize_t nargs, PyObject* kwnames) {
+    const bool has_kw = kwnames != nullptr && PyTuple_GET_SIZE(kwnames) > 0;
+    if (!has_kw && nargs == 9 && self->attend_fn && self->native_ctx && THPVariable_Check(args[1]) && THPVariable_Check(args[2]) &&
+        THPVariable_Check(args[3])) {
+        const long layer = PyLong_AsLong(args[0]);
+        const long heads = PyLong_AsLong(args[4]);
+        const double scale = PyFloat_AsDouble(args[5]);
+        const long factor = PyLong_AsLong(args[6]);
+        const int rl = PyObject_IsTrue(args[7]);
+        const int tapped = PyObject_IsTrue(args[8]);
+        if (PyErr_Occurred()) {
+            PyErr_Clear();
+        } else if (layer >= 0 && layer < static_cast<long>(self->acache->size())) {
+            bool steady = false;
+            at::Tensor out;
+            int rc = 0;
+            try {
+                const AttendCache& a = (*self->acache)[layer];
+                const at::Tensor& q = THPVariable_Unpack(args[1]);
+                const at::Tensor& k = THPVariable_Unpack(args[2]);
+                const at::Tensor& v = THPVariable_Unpack(args[3]);
+                const auto dev = q.device();
+                steady = a.valid && same3(q, a.q_size) && same3(k, a.k_size) && same3(v, a.k_size) &&
+                         static_cast<int>(q.scalar_type()) == a.dtype && static_cast<int>(k.scalar_type()) == a.dtype &&
+                         static_cast<int>(v.scalar_type()) == a.dtype &&
+                         static_cast<int>(dev.type()) == a.device_type && static_cast<int>(dev.index()) == a.device &&
+                         k.device() == dev && v.device() == dev && heads == a.heads && scale == a.scale && rl == a.round_logits &&
+                         q.is_contiguous() && k.is_contiguous() && v.is_contiguous() && q.has_storage() &&
+                         !(q.requires_grad() && c10::GradMode::is_enabled());
+                if (steady) {
+                    out = at::empty_like(q);
+                    void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+                    rc = self->attend_fn(self->native_ctx, static_cast<int>(layer), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                         out.data_ptr(), reinterpret_cast<const void*>(a.desc), 0, stream);
+                }
+            } catch (...) {
+                steady = false;
+            }
+            if (steady && rc == 0) {
+                if (tapped) {
+                    const int st = record_steady(self, layer, args[0], args[1], args[2], heads, scale, factor, rl);
+                    if (st < 0) return nullptr;
+                    if (st == 0) {                           // the tap of this layer is not in ITS steady state yet
+                        if (!self->slow_cb) { PyErr_SetString(PyExc_RuntimeError, "recorder is closed"); return nullptr; }
+                        PyObject* targs[7] = {args[0], args[1], args[2], args[4], args[5], args[6], args[7]};
+                        PyObject* r = PyObject_Vectorcall(self->slow_cb, targs, 7, nullptr);
+                        if (!r) return nullptr;
+                        Py_DECREF(r);
+                    }
+                }
+                return THPVariable_Wrap(out);
+            }
+            // a library error (or DAAM_E_UNSUPPORTED for an unaligned view): the engine repeats the call and reports / declines
+        }
+    }
+    if (!self->attend_slow_cb) { PyErr_SetString(PyExc_RuntimeError, "recorder has no attend path"); return nullptr; }
+    return PyObject_Vectorcall(self->attend_slow_cb, args, nargs, kwnames);
+}
+
+// set_native(ctx_addr, daam_attend_addr, attend_slow): the engine's native context and entry point (0, 0: none)
+PyObject* Recorder_set_native(Recorder* self, PyObject* args) {
+    unsigned long long ctx, fn;
+    PyObject* cb;
+    if (!PyArg_ParseTuple(args, "KKO", &ctx, &fn, &cb)) return nullptr;
+    self->native_ctx = reinterpret_cast<void*>(static_cast<uintptr_t>(ctx));
+    self->attend_fn = reinterpret_cast<AttendFn>(static_cast<uintptr_t>(fn));
+    Py_INCREF(cb);
+    Py_XSETREF(self->attend_slow_cb, cb);
+    Py_RETURN_NONE;
+}
+
+// set_attend_cache(layer, query, key, heads, scale, round_logits, desc_addr)
+PyObject* Recorder_set_attend_cache(Recorder* self, PyObject* args) {
+    int layer, rl;
+    long heads;
+    double scale;
+    unsigned long long desc;
+    PyObject *qo, *ko;
+    if (!PyArg_ParseTuple(args, "iOOldpK", &layer, &qo, &ko, &heads, &scale, &rl, &desc)) return nullptr;
+    if (layer < 0 || layer >= static_cast<int>(self->acache->size()) || !THPVariable_Check(qo) || !THPVariable_Check(ko)) {
+        PyErr_SetString(PyExc_ValueError, "set_attend_cache: bad layer or tensors");
+        return nullptr;
+    }
+    const at::Tensor& q = THPVariable_Unpack(qo);
+    const at::Tensor& k = THPVariable_Unpack(ko);
+    if (q.dim() != 3 || k.dim() != 3) { PyErr_SetString(PyExc_ValueError, "set_attend_cache: query / key must be 3-d"); return nullptr; }
+    AttendCache& a = (*self->acache)[layer];
+    for (int i = 0; i < 3; ++i) { a.q_size[i] = q.sizes()[i]; a.k_size[i] = k.sizes()[i]; }
+    a.dtype = static_cast<int>(q.scalar_type());
+    a.device_type = static_cast<int>(q.device().type());
+    a.device = static_cast<int>(q.device().index());
+    a.heads = heads; a.scale = scale; a.round_logits = rl; a.desc = desc;
+    a.valid = desc != 0;
+    Py_RETURN_NONE;
 }
 
 // set_cache(layer, query, key, heads, scale, factor, round_logits, desc_addr)
@@ -360,6 +493,7 @@ PyObject* Recorder_reset_touched(Recorder* self, PyObject*) {
 
 PyObject* Recorder_invalidate(Recorder* self, PyObject*) {             // forget every layer's cached call shape
     for (auto& c : *self->cache) c.valid = false;
+    for (auto& a : *self->acache) a.valid = false;
     Py_RETURN_NONE;
 }
 
@@ -390,6 +524,10 @@ PyObject* Recorder_held_bytes(Recorder* self, PyObject*) { return PyLong_FromLon
 PyMethodDef Recorder_methods[] = {
     {"tap", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(Recorder_tap)), METH_FASTCALL | METH_KEYWORDS,
      "tap(layer, query, key, heads, scale, factor, round_logits=True): record one deferred tap"},
+    {"attend", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(Recorder_attend)), METH_FASTCALL | METH_KEYWORDS,
+     "attend(layer, query, key, value, heads, scale, factor, round_logits, tapped): daam_attend + record the deferred tap"},
+    {"set_native", reinterpret_cast<PyCFunction>(Recorder_set_native), METH_VARARGS, "native context, daam_attend address, Python attend path"},
+    {"set_attend_cache", reinterpret_cast<PyCFunction>(Recorder_set_attend_cache), METH_VARARGS, "remember a layer's validated attend call"},
     {"set_cache", reinterpret_cast<PyCFunction>(Recorder_set_cache), METH_VARARGS, "remember a layer's validated call shape"},
     {"record", reinterpret_cast<PyCFunction>(Recorder_record), METH_VARARGS, "record a tap the engine validated"},
     {"pending", reinterpret_cast<PyCFunction>(Recorder_pending), METH_O, "recorded steps of one layer"},

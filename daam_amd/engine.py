@@ -132,6 +132,21 @@ class HeatMapEngine:
                 self._fast.set_window(self._window)
                 self._fast.set_budget(self.defer_bytes)
                 self.tap_qk = self._fast.tap
+                # daam_attend from C++ too (the recorder gets the context and the entry point once the context exists)
+                self._attend_addr = 0
+                try:
+                    self._attend_addr = ctypes.cast(self.lib.daam_attend, ctypes.c_void_p).value or 0
+                except (ctypes.ArgumentError, TypeError, AttributeError):
+                    pass                                   # not a ctypes library (tests drive the engine with a recording fake)
+                self.attend = self._fast.attend
+                self._sync_native()
+
+    def _sync_native(self) -> None:
+        """Tell the C++ recorder which native context (if any) its ``attend`` launches on."""
+        if self._fast is not None:
+            me = weakref.ref(self)
+            ctx = self.ctx.value if self.ctx is not None and getattr(self.ctx, 'value', None) else 0
+            self._fast.set_native(ctx or 0, self._attend_addr if ctx else 0, lambda *a, **k: HeatMapEngine.attend(me(), *a, **k))    # the Python method: the recorder's slow path
 
     # ---- lifetime --------------------------------------------------------------------------
     def _require_device(self, t: torch.Tensor) -> None:
@@ -157,6 +172,7 @@ class HeatMapEngine:
             # whatever the previous owner queued (on its stream) comes first
             self._current_stream().wait_event(st['event'])
             nat.check(self.lib.daam_reset(self.ctx, self.stream))      # sums start from zero (lazily, like clear())
+            self._sync_native()
             return
         ctx = nat.c_void_p()
         with torch.cuda.device(self.device):
@@ -164,6 +180,7 @@ class HeatMapEngine:
                                                _DTYPE_CODE[self.acc_dtype],
                                                nat.byref(ctx)))
         self.ctx = ctx
+        self._sync_native()
 
     def _park_key(self) -> tuple:
         return (str(self.device), self.n_layers, self.tokens, self.out_side, self.acc_dtype)
@@ -182,6 +199,7 @@ class HeatMapEngine:
             else:
                 self.lib.daam_ctx_destroy(self.ctx)
             self.ctx = None
+            self._sync_native()
         self.acc.clear()
         self.layer_info.clear()
         self.touched.clear()
@@ -416,6 +434,9 @@ class HeatMapEngine:
                 ref = nat.byref(desc)
         entry = (query.shape, key.shape, query.dtype, heads, scale, round_logits, ref, desc)
         self._att_cache[layer] = entry
+        if self._fast is not None:
+            self._fast.set_attend_cache(layer, query, key, int(heads), float(scale), bool(round_logits),
+                                        ctypes.addressof(desc) if desc is not None else 0)
         return entry
 
     def _launch_stream(self):

@@ -211,3 +211,42 @@ def test_processor_routes_leave_identical_sums(monkeypatch):
         assert torch.equal(a, b)
     for a, b in zip(deferred[2], stock[2]):
         assert (a.float() - b.float()).abs().max().item() <= 2e-3 * b.float().abs().max().item()
+
+
+def test_cxx_recorder_runs_attend_in_the_steady_state():
+    """On a deferred trace ``engine.attend`` IS the C++ recorder's entry point: after a layer's first call (which builds
+    the descriptor in Python) the Python method is not entered again, the outputs are those of the Python path, and the
+    recorded taps leave the same sums."""
+    from daam_amd.engine import HeatMapEngine
+    eng = HeatMapEngine(2, defer_steps=8)
+    if eng._fast is None:
+        pytest.skip('daam_amd._fastpath is not built')
+    assert eng.attend == eng._fast.attend
+    entered = []
+    orig = HeatMapEngine.attend
+
+    def counting(self, *a, **k):
+        entered.append(a[0])
+        return orig(self, *a, **k)
+    HeatMapEngine.attend = counting
+    try:
+        ref = _engine(n_layers=2, defer_steps=0)           # immediate engine: Python attend with the fused tap
+        outs, wants = [], []
+        for step in range(4):
+            for layer, (heads, hw) in enumerate(((10, 1024), (5, 4096))):
+                q, k, v = _inputs(2, heads, hw, seed=10 * step + layer)
+                outs.append(eng.attend(layer, q, k, v, heads, 0.125, 1, True, True))
+                wants.append(orig(ref, layer, q, k, v, heads, 0.125, 1, True, True))
+        assert entered == [0, 1]                           # one Python entry per layer, then C++ only
+        assert eng.pending_taps == 8
+        for a, b in zip(outs, wants):
+            assert a is not None and torch.equal(a, b)
+        got, want = dict(eng.items()), dict(ref.items())
+        assert list(got) == list(want) and all(torch.equal(got[key], want[key]) for key in got)
+        # a call the kernel does not take still reaches Python and declines
+        q, k, v = _inputs(2, 10, 1024, seed=3)
+        assert eng.attend(0, q.float(), k.float(), v.float(), 10, 0.125, 1, True, True) is None
+    finally:
+        HeatMapEngine.attend = orig
+    eng.close()
+    ref.close()
