@@ -89,6 +89,27 @@ def attention_probs(q: np.ndarray, k: np.ndarray, scale: float, pipe_dtype=np.fl
     return _cast(p, pipe_dtype)
 
 
+def attention_output(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: float, pipe_dtype=np.float32,
+                     upcast_attention: bool = False, mask: Optional[np.ndarray] = None) -> np.ndarray:
+    """What the reference's processor computes between the projections and ``to_out``: ``torch.bmm(attention_probs,
+    value)`` (trace.py:296) on the probabilities of ``get_attention_scores`` (trace.py:276), in the pipeline dtype.
+
+    q ``[BH, hw, d]``, k / v ``[BH, T, d]`` -> ``[BH, hw, d]`` in ``pipe_dtype``: the probabilities are rounded to the
+    pipeline dtype (``attention_probs``), the product with ``value`` is accumulated wide and rounded ONCE (a GEMM with
+    f32 accumulation; summed in f64 here, which differs from any f32 order by less than the final rounding)."""
+    probs = attention_probs(q, k, scale, pipe_dtype, upcast_attention, mask)
+    wide = np.matmul(probs.astype(np.float64), v.astype(np.float64))
+    if not is_bf16(pipe_dtype) and np.dtype(pipe_dtype) == np.float64:
+        return wide
+    return _cast(wide.astype(np.float32), pipe_dtype)
+
+
+def batch_to_head_dim(t: np.ndarray, heads: int) -> np.ndarray:
+    """diffusers ``Attention.batch_to_head_dim`` (trace.py:297): ``[B*H, S, d] -> [B, S, H*d]``."""
+    bh, s, d = t.shape
+    return t.reshape(bh // heads, heads, s, d).transpose(0, 2, 1, 3).reshape(bh // heads, s, heads * d)
+
+
 # --------------------------------------------------------------------------------------
 # K3: UNetCrossAttentionHooker._unravel_attn  (trace.py:219-244)
 # --------------------------------------------------------------------------------------
@@ -335,14 +356,16 @@ def locate(unet, restrict=None, locate_middle_block: bool = False):
 
 
 def replay_generation(pipe, steps: int, pipe_dtype, acc_dtype=None, restrict=None,
-                      locate_middle_block: bool = False) -> "RawMaps":
+                      locate_middle_block: bool = False, outputs: Optional[list] = None) -> "RawMaps":
     """Drive the oracle over the same synthetic inputs a fake pipeline feeds its UNet
     (``oracle/fake_diffusers.py``): per step, every cross-attention in execution order;
-    hooked ones (per ``locate``) are tapped with ``layer_idx`` = locator position."""
+    hooked ones (per ``locate``) are tapped with ``layer_idx`` = locator position.
+    ``outputs``: a list that receives what every processor call of the LAST step returns (trace.py:296-304:
+    ``to_out(batch_to_head_dim(bmm(probs, value)))``), execution order, hooked or not."""
     import torch
     np_dtype = {torch.float16: np.float16, torch.float32: np.float32, torch.bfloat16: BF16,
                 torch.float64: np.float64}.get(pipe_dtype, pipe_dtype)
-    as_np = (lambda t: t.float().cpu().numpy()) if is_bf16(np_dtype) else (lambda t: t.cpu().numpy())
+    as_np = (lambda t: t.detach().float().cpu().numpy()) if is_bf16(np_dtype) else (lambda t: t.detach().cpu().numpy())
     raw = RawMaps(np_dtype if acc_dtype is None else acc_dtype)
     modules, _ = locate(pipe.unet, restrict, locate_middle_block)
     index_of = {id(m): i for i, m in enumerate(modules)}
@@ -351,10 +374,21 @@ def replay_generation(pipe, steps: int, pipe_dtype, acc_dtype=None, restrict=Non
     for step in range(steps):
         for i, spec in enumerate(order):
             li = index_of.get(id(spec.module))
-            if li is None:
+            want_out = outputs is not None and step == steps - 1
+            if li is None and not want_out:
                 continue
             a = spec.module
             q = as_np(a.head_to_batch_dim(a.to_q(pipe.hidden_states(i, spec, step))))
             k = as_np(a.head_to_batch_dim(a.to_k(pipe.context(i, spec))))
-            tap(raw, li, q, k, a.scale, lat, np_dtype, upcast_attention=getattr(a, 'upcast_attention', False))
+            upcast = getattr(a, 'upcast_attention', False)
+            if li is not None:
+                tap(raw, li, q, k, a.scale, lat, np_dtype, upcast_attention=upcast)
+            if want_out:
+                v = as_np(a.head_to_batch_dim(a.to_v(pipe.context(i, spec))))
+                mixed = batch_to_head_dim(attention_output(q, k, v, a.scale, np_dtype, upcast_attention=upcast), a.heads)
+                w, b = as_np(a.to_out[0].weight.detach()), a.to_out[0].bias
+                proj = np.matmul(mixed.astype(np.float64), w.astype(np.float64).T)
+                if b is not None:
+                    proj = proj + as_np(b.detach()).astype(np.float64)
+                outputs.append(proj if np_dtype == np.float64 else _cast(proj.astype(np.float32), np_dtype))
     return raw

@@ -2,8 +2,8 @@
 ``batch_to_head_dim`` of the reference's ``UNetCrossAttentionHooker.__call__`` (daam/trace.py:276,296-297) -- with the
 heat-map tap (:289-294, heatmap.py:153-156) fused into the same kernel.  Checked against
 
-* a float64 restatement with the reference's rounding points (numpy, this file: logits -> fp16, softmax, probabilities ->
-  fp16, value product in high precision -> fp16),
+* the numpy oracle (``oracle/heatmap_oracle.py::attention_output``: logits -> fp16, softmax, probabilities -> fp16, value product
+  accumulated wide -> fp16; pinned on the CPU to what the unmodified reference's processor returned),
 * the reference's own sequence of torch ops run in PyTorch-ROCm eager on the same inputs (``oracle/torch_hooks.py``),
 * the library's stand-alone tap (``daam_tap_qk``): the fused tap must leave BIT-IDENTICAL running sums.
 
@@ -47,16 +47,13 @@ def _reference_eager(q, k, v, heads, scale):
 
 
 def _restated_f64(q, k, v, heads, scale, round_logits=True):
-    """float64 arithmetic, the reference's rounding points."""
-    qh, kh, vh = (_to_heads(t, heads).cpu().numpy().astype(np.float64) for t in (q, k, v))
-    logits = np.einsum('bpd,btd->bpt', qh, kh).astype(np.float32) * np.float32(scale)      # f32 accumulate, alpha in f32
-    if round_logits:
-        logits = logits.astype(np.float16)
-    x = logits.astype(np.float64)
-    e = np.exp(x - x.max(-1, keepdims=True))
-    probs = (e / e.sum(-1, keepdims=True)).astype(np.float16)
-    out = np.einsum('bpt,btd->bpd', probs.astype(np.float64), vh).astype(np.float16)
-    return _from_heads(torch.from_numpy(out), heads), probs
+    """The numpy oracle (``oracle/heatmap_oracle.py::attention_output``, pinned to the processor outputs of the unmodified
+    reference by ``tests/test_oracle_golden.py``): the reference's rounding points, wide accumulation."""
+    from oracle import heatmap_oracle as ho
+    qh, kh, vh = (_to_heads(t, heads).cpu().numpy() for t in (q, k, v))
+    probs = ho.attention_probs(qh, kh, scale, np.float16, upcast_attention=not round_logits)
+    out = ho.attention_output(qh, kh, vh, scale, np.float16, upcast_attention=not round_logits)
+    return torch.from_numpy(ho.batch_to_head_dim(out, heads)), probs
 
 
 def _engine(n_layers=1, accumulate='exact', defer_steps=0):

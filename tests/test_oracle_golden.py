@@ -54,6 +54,29 @@ def test_oracle_matches_reference(golden_case):
                                    err_msg=f'{name}:{vn}')
 
 
+def test_oracle_processor_outputs_match_reference(golden_case):
+    """``ho.attention_output`` (+ ``batch_to_head_dim`` + the output projection): what the reference's processor RETURNED
+    for every cross-attention call of the last step (trace.py:296-304), against the rows and sums recorded when the
+    unmodified reference ran."""
+    name, z, meta = golden_case
+    if 'out_sums' not in z or meta['dtype'] == 'bfloat16':
+        pytest.skip('case carries no processor outputs')
+    import torch
+    from oracle.make_golden import OUT_SAMPLE_ROWS
+    pipe = golden_pipe(meta)
+    outs = []
+    ho.replay_generation(pipe, meta['steps'], getattr(torch, meta['dtype']), locate_middle_block=bool(meta.get('heads')),
+                         outputs=outs)
+    assert len(outs) == len(z['out_sums'])
+    rel = 1e-5 if meta['dtype'] == 'float32' else 2e-3
+    for i, o in enumerate(outs):
+        want = z[f'out_rows_{i}']
+        got = o[-1, :OUT_SAMPLE_ROWS].astype(np.float32)
+        assert np.abs(got - want).max() <= rel * max(float(np.abs(want).max()), 1e-6), f'{name}: call {i}'
+        sq = float((o.astype(np.float64) ** 2).sum())
+        assert abs(sq - z['out_sums'][i, 1]) <= 4 * rel * z['out_sums'][i, 1], f'{name}: call {i}'
+
+
 def test_oracle_word_heat_map(golden_case):
     name, z, meta = golden_case
     pipe = golden_pipe(meta)
