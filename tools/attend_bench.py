@@ -90,6 +90,7 @@ def measure(steps=50, reps=5, dev=None, only=None):
     res['algorithmic_bytes_per_step'] = dict(attend=qo + kv, attend_fused_tap=qo + kv + rmw)
     for name, b in (('attend', qo + kv), ('attend_fused_tap', qo + kv + rmw)):
         res[name]['gbps'] = round(b / (res[name]['ms_per_step'] * 1e-3) / 1e9, 1)
+        res[name]['frac_of_hbm_peak'] = round(res[name]['gbps'] / 8000.0, 4)   # loop time incl. launch gaps: a lower bound for the kernel
     res['fused_tap_cost_ms_per_step'] = round(res['attend_fused_tap']['ms_per_step'] - res['attend']['ms_per_step'], 4)
     # parity of what the two paths left behind: the fused sums equal the stand-alone tap's, bit for bit
     a, b = dict(fused.items()), dict(plain.items())
