@@ -46,8 +46,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
 
 WORKLOADS = {
+    # BASELINE.json configs[2] (the headline), configs[4] (100 steps; 25 distinct step sets = 39 GB, cycled: a set is long
+    # gone from the 256 MB of Infinity Cache when it recurs), configs[1]
     'sdxl1024': dict(kind='sdxl', latent=128, label='SDXL-base-1.0 topology 1024x1024, 60 layers / 1100 keys'),
-    'sdxl2048': dict(kind='sdxl', latent=256, label='SDXL-base-1.0 topology 2048x2048, 60 layers / 1100 keys'),
+    'sdxl2048': dict(kind='sdxl', latent=256, label='SDXL-base-1.0 topology 2048x2048, 60 layers / 1100 keys', denoise_steps=100,
+                     pool_cap=25, min_warm=4),
     'sd15': dict(kind='sd15', latent=64, label='SD-v1.5 topology 512x512, 15 layers / 120 keys'),
 }
 
@@ -181,73 +184,67 @@ def cpu_model() -> str:
     return 'unknown'
 
 
-def _one_thread_baseline(th, layers, denoise_steps):
-    """The same port on ONE host thread, on a sample a tenth the size: every 10th hooked layer for one
-    denoising step and compute_global_heat_map over those layers' keys, scaled by the work ratio."""
-    import torch as _t
-    prev = _t.get_num_threads()
-    _t.set_num_threads(1)
+def _physical_cores() -> int:
     try:
-        sub = layers[::10]
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def _port_sample(th, layers, denoise_steps, threads, sample_steps, cache):
+    """``sample_steps`` denoising steps of _unravel_attn + per-head update over every hooked layer and one
+    compute_global_heat_map over all keys, on ``threads`` host threads; extrapolated to ``denoise_steps``."""
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
         raw = th.RawMaps()
-        probs = {}
-        t0 = time.perf_counter()
-        for (layer, heads, side, d) in sub:
-            key = (heads, side)
-            if key not in probs:
-                probs[key] = _t.rand(2 * heads, side * side, 77)
-        t_gen = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        for (layer, heads, side, d) in sub:
-            th.tap(raw, layer, probs[(heads, side)], 4096)
-        t_tap = time.perf_counter() - t0
+        t_tap = 0.0
+        for _ in range(sample_steps):
+            for (layer, heads, side, d) in layers:
+                t0 = time.perf_counter()
+                th.tap(raw, layer, cache[(heads, side)], 4096)
+                t_tap += time.perf_counter() - t0
         t0 = time.perf_counter()
         th.global_heat_map(raw, 4096)
         t_fin = time.perf_counter() - t0
+        n_keys = len(raw)
     finally:
-        _t.set_num_threads(prev)
-    elems_all = sum(h * s * s for _, h, s, _ in layers)
-    elems_sub = sum(h * s * s for _, h, s, _ in sub)
-    ratio = elems_all / elems_sub
-    per_step, fin = t_tap * ratio, t_fin * ratio
-    return dict(value=round(1.0 / (per_step * denoise_steps + fin), 6), unit='maps/s', cores=1,
-                ms_per_denoise_step=round(per_step * 1e3, 2), finalize_s=round(fin, 3),
-                sample=f'{len(sub)} of {len(layers)} layers x 1 step + finalize of their {len(raw)} keys, scaled x{ratio:.1f} by element count')
+        torch.set_num_threads(prev)
+    per_step = t_tap / sample_steps
+    return dict(value=1.0 / (per_step * denoise_steps + t_fin), unit='maps/s', cores=threads,
+                ms_per_denoise_step=per_step * 1e3, finalize_s=t_fin, keys=n_keys, cpu_seconds_sampled=round(t_tap + t_fin, 2))
 
 
 def cpu_baseline(kind, latent, denoise_steps, sample_steps=2, eager_device=None):
     """THE baseline leg (the only place bench.py touches oracle/, and only to time it): the reference's hook
-    path (torch port, oracle/torch_hooks.py) on the host cores, fp32 (the reference's CPU-runnable
+    path (torch port, oracle/torch_hooks.py; its op sequence timed against the unmodified reference on the build box:
+    profiles/r03_port_vs_reference_cpu.json) on the host cores, fp32 (the reference's CPU-runnable
     configuration): `sample_steps` denoising steps of unravel + per-head update over every hooked layer, and
-    one compute_global_heat_map.  With `eager_device` the same port is also timed in PyTorch-ROCm eager on the
+    one compute_global_heat_map -- at 1 thread, at the physical core count and at every hardware thread; the headline
+    ``value`` / ``cores`` is the BEST of the three (the op sequence is thousands of small tensor ops: it is fastest on one
+    thread, and oversubscribed at 128).  With `eager_device` the same port is also timed in PyTorch-ROCm eager on the
     MI355X (the denominator of the >= 20x target), returned under 'eager_mi355x'."""
     from oracle import torch_hooks as th
     eager = _port_eager_on_device(th, kind, latent, denoise_steps, eager_device) if eager_device is not None else None
     layers = th.execution_order(th.topology(kind, latent))
-    lat_hw = 4096
-    cores = torch.get_num_threads()
     cache = {}
-    raw = th.RawMaps()
-    t_tap = 0.0
-    for _ in range(sample_steps):
-        for (layer, heads, side, d) in layers:
-            key = (heads, side)
-            if key not in cache:
-                cache[key] = torch.rand(2 * heads, side * side, 77)
-            t0 = time.perf_counter()
-            th.tap(raw, layer, cache[key], lat_hw)
-            t_tap += time.perf_counter() - t0
-    t0 = time.perf_counter()
-    th.global_heat_map(raw, lat_hw)
-    t_fin = time.perf_counter() - t0
-    per_step = t_tap / sample_steps
-    total = per_step * denoise_steps + t_fin
-    out = dict(value=1.0 / total, unit='maps/s', cores=cores, kind='port', cpu=cpu_model(),
-               one_thread=_one_thread_baseline(th, layers, denoise_steps),
-               ms_per_denoise_step=per_step * 1e3, finalize_s=t_fin,
+    for (_, heads, side, _) in layers:
+        if (heads, side) not in cache:
+            cache[(heads, side)] = torch.rand(2 * heads, side * side, 77)
+    all_threads = os.cpu_count() or torch.get_num_threads()
+    counts = sorted({1, _physical_cores(), all_threads})
+    runs = [_port_sample(th, layers, denoise_steps, n, sample_steps, cache) for n in counts]
+    best = max(runs, key=lambda r: r['value'])
+    out = dict(value=best['value'], unit='maps/s', cores=best['cores'], kind='port', cpu=cpu_model(),
+               ms_per_denoise_step=best['ms_per_denoise_step'], finalize_s=best['finalize_s'],
+               by_threads={str(r['cores']): {k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items() if k != 'unit'} for r in runs},
                sample=f'{sample_steps} denoising steps x {len(layers)} layers of _unravel_attn+update (fp32, torch '
-                      f'{torch.__version__}, {cores} threads) + 1 compute_global_heat_map over {len(raw)} keys; '
-                      f'extrapolated to {denoise_steps} steps')
+                      f'{torch.__version__}) + 1 compute_global_heat_map over {best["keys"]} keys, extrapolated to {denoise_steps} steps; '
+                      f'run at {counts} host threads, best reported ({best["cores"]})')
     if eager is not None:
         out['eager_mi355x'] = eager
     return out
@@ -328,12 +325,13 @@ def integrated_overhead(device, steps=50, reps=9):
                                                 round(diffs[(3 * len(diffs)) // 4] / steps * 1e3, 3)])
 
 
-def _respawn_under_launcher(n):
+def _respawn_under_launcher(n, shared_device):
     """``python bench.py --gpus N`` (N > 1) without a launcher: run N ranks of this script under torch.distributed.run."""
     import socket
     import subprocess
-    if torch.cuda.device_count() < n:
-        raise SystemExit(f'--gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible: refusing to report another n_gpus')
+    if torch.cuda.device_count() < n and not shared_device:
+        raise SystemExit(f'--gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible: refusing to report another n_gpus '
+                         '(--shared-device runs N ranks on one device for functional tests of the multi-rank path)')
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
@@ -356,186 +354,309 @@ def load_profile(name):
     return rec, f'profiles/{name} (rocprofv3 --pmc passes of this build, csrc {rec["csrc_sha"]}; not re-measured in this run)'
 
 
+COUNTER_FILES = ('r03_counters.json', 'r02_counters.json')      # newest first; only one matching this build is used
+
+
+def load_counters():
+    note = None
+    for name in COUNTER_FILES:
+        prof, n = load_profile(name)
+        if prof is not None:
+            return prof, n
+        note = note or n
+    return None, note
+
+
+def default_defer_bytes(device):
+    """Byte budget of the recorded Q / K for the bench engines: what ``daam_amd.trace`` gives a pipeline on an otherwise
+    empty MI355X (40 % of the device memory, daam_amd/trace.py::_default_defer_bytes).  The bench's synthetic Q / K are
+    resident BEFORE the engine records them (recording pins nothing extra), so the rule is applied to the device's total."""
+    return int(torch.cuda.get_device_properties(device).total_memory * 0.4)
+
+
+class Comm:
+    """The bench's three collectives (barrier, all_gather of the final maps, MAX of the elapsed times) over ``nccl`` (= RCCL,
+    device tensors, the production path) or ``gloo`` (functional runs: several ranks on ONE device, where RCCL refuses a
+    duplicate GPU; device tensors are staged through the host)."""
+
+    def __init__(self, backend, device):
+        import torch.distributed as dist
+        self.dist, self.backend, self.device = dist, backend, device
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group('gloo')
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def all_gather(self, mine):
+        out = torch.empty(self.world * mine.shape[0], *mine.shape[1:], device=mine.device, dtype=mine.dtype)
+        if self.backend == 'nccl':
+            self.dist.all_gather_into_tensor(out, mine)
+        else:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(host, mine.cpu())
+            out.copy_(host)
+        return out
+
+    def max(self, value):
+        t = torch.tensor([value], dtype=torch.float64, device=self.device if self.backend == 'nccl' else 'cpu')
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
+def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, rank=0, world=1, detail=True):
+    """Warm up, time ``gens`` generations of workload ``name`` on this rank (+ the gather of the final maps when there are
+    several ranks) between barriers, then -- rank 0, ``detail`` -- the per-kernel measurements.  Returns the pieces of the
+    JSON line (rank 0) or None."""
+    from daam_amd.engine import HeatMapEngine
+    wl = WORKLOADS[name]
+    layers = topology(wl['kind'], wl['latent'])
+    latent_side = 64
+    pool = args.pool if args.pool > 0 else min(denoise_steps, wl.get('pool_cap', denoise_steps))
+    sets = make_inputs(layers, pool, device, seed=1234 + rank)
+    defer_bytes = args.defer_bytes if args.defer_bytes > 0 else default_defer_bytes(device)
+    eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=args.accumulate, defer_steps=args.defer,
+                        defer_bytes=defer_bytes)
+    calls = call_lists(layers, sets, latent_side)
+    # untimed: the W warm-up generations, plus whatever it takes to reach steady state -- the first call
+    # creates the context and loads the code objects (36 ms), the GPU needs ~10 generations from idle to its
+    # sustained clock, and the one-off costs of the result stack / the RCCL communicator are paid here too
+    warm = [one_generation(eng, calls, denoise_steps) for _ in range(max(warmup, 1))]
+    for _ in range(max(0, wl.get('min_warm', 20) - len(warm))):
+        one_generation(eng, calls, denoise_steps)
+    w = torch.stack(warm[:2])
+    if comm:
+        comm.all_gather(w)
+    del warm, w
+    launches0 = eng.last_flush()['launches']
+    torch.cuda.synchronize()
+    if comm:
+        comm.barrier()
+    torch.cuda.synchronize()
+    results = []
+    t0 = time.perf_counter()
+    for _ in range(gens):
+        results.append(one_generation(eng, calls, denoise_steps))
+    mine = torch.stack(results)
+    gathered = comm.all_gather(mine) if comm else None
+    torch.cuda.synchronize()
+    if comm:
+        comm.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    launches_per_gen = (eng.last_flush()['launches'] - launches0) / gens     # what the engine really launched
+    flush = eng.last_flush()
+    if comm:
+        elapsed = comm.max(elapsed)
+        # untimed tail: every rank finds its own maps in its slice of the gathered tensor (rank-major: the all_gather layout)
+        if not torch.equal(gathered[rank * gens:(rank + 1) * gens], mine):
+            raise SystemExit(f'rank {rank}: gathered maps differ from the maps this rank computed')
+        if not bool(torch.isfinite(gathered).all()) or float(gathered.abs().sum()) == 0.0:
+            raise SystemExit(f'rank {rank}: gathered maps are empty or not finite')
+    del results, mine, gathered
+    if rank != 0:
+        eng.close()
+        return None
+
+    acc_bytes = 2 if args.accumulate == 'exact' else 4
+    out = dict(label=wl['label'], elapsed=elapsed, gens=gens, denoise_steps=denoise_steps,
+               value=world * gens / elapsed, ms_per_step=elapsed / gens * 1e3, keys=sum(h for _, h, _, _ in layers))
+    # steps one tap launch covers: the step window, or fewer when the recorded Q / K reach the engine's
+    # byte budget (a launch is then forced at the next step boundary)
+    step_bytes = sum(q.numel() * q.element_size() + k.numel() * k.element_size() for q, k in sets[0])
+    spl = max(1, min(args.defer, denoise_steps, 64, -(-eng.defer_bytes // step_bytes)))
+    out['steps_per_launch'] = spl
+    if args.defer > 0:
+        expect = -(-denoise_steps // spl)
+        if round(launches_per_gen) != expect:
+            raise SystemExit(f'{name}: {launches_per_gen} tap launches per generation, expected {expect}')
+        launches_per_gen = expect
+        fresh = launches_per_gen == 1
+        tap_ms = measure_tap_kernel(eng, calls, spl, reps=10 if detail else 4, fresh=fresh)
+        bytes_launch, qk_bytes, acc_total = tap_bytes(layers, spl, acc_bytes, fresh=fresh)
+        if launches_per_gen > 1:
+            # a generation of several launches: the first writes the sums (fresh), the others read-modify-write them, the
+            # last may be shorter -- algorithmic bytes and time of the WHOLE generation's launches, reported per launch
+            last = denoise_steps - spl * (launches_per_gen - 1)
+            gen_bytes = (denoise_steps * qk_bytes + acc_total * (2 * launches_per_gen - 1))
+            tap_ms_last = measure_tap_kernel(eng, calls, last, reps=4, fresh=False) if last != spl else tap_ms
+            tap_ms_first = measure_tap_kernel(eng, calls, spl, reps=4, fresh=True)
+            gen_ms = tap_ms_first + (launches_per_gen - 2) * tap_ms + tap_ms_last
+            out['tap_ms_per_generation'] = gen_ms
+            bytes_launch, tap_ms_avg = gen_bytes / launches_per_gen, gen_ms / launches_per_gen
+        else:
+            tap_ms_avg = tap_ms
+            out['tap_ms_per_generation'] = tap_ms
+    else:
+        # immediate mode: 1 launch per layer call; time a whole denoising step of launches
+        stream = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        one_generation(eng, calls, 2)
+        e0.record(stream)
+        reps = 10
+        for r in range(reps):
+            for a in calls[r % len(calls)]:
+                eng.tap_qk(*a)
+        e1.record(stream)
+        e1.synchronize()
+        tap_ms = tap_ms_avg = e0.elapsed_time(e1) / reps / len(layers)
+        bytes_launch, qk_bytes, acc_total = tap_bytes(layers, 1, acc_bytes, fresh=False)
+        bytes_launch /= len(layers)
+        launches_per_gen = denoise_steps * len(layers)
+        out['tap_ms_per_generation'] = tap_ms * launches_per_gen
+    achieved = bytes_launch / (tap_ms_avg * 1e-3) / 1e9
+    survey_bytes = spl * (qk_bytes + 2 * acc_total) if args.defer > 0 else bytes_launch   # SURVEY 8(d): RMW per step
+    key = f'{name}:defer{spl}:{args.accumulate}'
+    prof, prof_note = load_counters()
+    rec = (prof or {}).get('workloads', {}).get(key)
+    traffic = rec.get('tap_bytes_per_launch') if rec else None
+    tap_kernel = ('tap_d64_kernel (16x16x32 MFMA tiles, head_dim 64)' if wl['kind'] == 'sdxl'
+                  else 'tap_d64_kernel (head_dim 40) + tap_wide_kernel<3|5> (head_dim 80 / 160), one flush = 3 kernels side by side')
+    out['roofline'] = dict(bound='hbm', kernel=tap_kernel,
+                           achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
+                           traffic=traffic, traffic_measured_in_run=False,
+                           traffic_source=prof_note if rec else (prof_note or 'no PMC pass committed for this workload'),
+                           bytes_per_launch=int(bytes_launch), ms_per_launch=round(tap_ms_avg, 4),
+                           steps_per_launch=spl, launches_per_generation=launches_per_gen,
+                           kernels_per_launch=flush['kernels'], kernels_on_side_streams=flush['side_streams'],
+                           achieved_at_survey_8d_bytes=round(survey_bytes / (tap_ms * 1e-3) / 1e9, 1))
+    # ---- issue-rate roofline of the same launch: the deferred tap keeps the sums in registers, so its HBM work is the
+    # Q / K stream only and the kernel is bound by instruction issue (softmax VALU + MFMA).  Floor = (VALU busy cycles +
+    # MFMA instructions x the ~10 cycles each keeps the VALU port closed, tools/ubench_issue) per SIMD / shader clock.
+    roofline_issue = None
+    if args.defer > 0:
+        mon = ClockMonitor(eng, window_ms=40.0)                  # second pass with the monitor wave running beside the kernel
+        measure_tap_kernel(eng, calls, spl, reps=8 if detail else 3, fresh=launches_per_gen == 1)
+        clock = mon.read()
+        roofline_issue = dict(bound='issue', kernel=tap_kernel, clock=clock, ms_per_launch=round(tap_ms, 4))
+        if rec and clock and rec.get('tap_valu_busy_cycles_per_simd'):
+            cyc = rec['tap_valu_busy_cycles_per_simd'] + 10.0 * rec.get('tap_mfma_per_simd', 0)
+            floor_ms = cyc / (clock['mhz_median_under_load'] * 1e3)
+            roofline_issue.update(valu_busy_cycles_per_simd=rec['tap_valu_busy_cycles_per_simd'],
+                                  valu_insts_per_simd=rec.get('tap_valu_insts_per_simd'),
+                                  mfma_insts_per_simd=rec.get('tap_mfma_per_simd'), mfma_issue_block_cycles=10,
+                                  floor_ms=round(floor_ms, 4), frac=round(floor_ms / tap_ms, 4), source=prof_note,
+                                  counters_measured_in_run=False)
+        else:
+            roofline_issue['note'] = prof_note or 'no PMC pass committed for this workload'
+    out['roofline_issue'] = roofline_issue
+    # host cost of the per-layer call path for one generation (launches are asynchronous)
+    torch.cuda.synchronize()
+    th0 = time.perf_counter()
+    for t in range(denoise_steps):
+        for a in calls[t % len(calls)]:
+            eng.tap_qk(*a)
+    eng.flush()
+    out['host_ms'] = (time.perf_counter() - th0) * 1e3
+    torch.cuda.synchronize()
+    fin_ms = measure_finalize(eng, reps=40 if detail else 10)
+    mon = ClockMonitor(eng, window_ms=10.0, period_us=50)       # the clock in a second pass: the monitor wave is kept out of the timing
+    measure_finalize(eng, reps=60 if detail else 10)
+    fin_clock = mon.read()
+    fin_bytes = acc_total + 77 * 64 * 64 * 4
+    fin_gbs = fin_bytes / (fin_ms * 1e-3) / 1e9
+    fin_kernel = {'sdxl1024': 'table upload + zeroing, finalize_up32_same_kernel (x2 MFMA class and same-size class in one launch)',
+                  'sdxl2048': 'table upload + zeroing, finalize_down2 (128 -> 64) + finalize_same_kernel',
+                  'sd15': 'table upload + zeroing, finalize_same / finalize_up32_mfma / finalize_up_kernel<16>'}[name]
+    fin_issue = dict(bound='issue', kernel=fin_kernel, clock=fin_clock, ms_per_launch=round(fin_ms, 4))
+    if rec and fin_clock and rec.get('finalize_valu_busy_cycles_per_simd'):
+        n_mfma = rec.get('finalize_mfma_per_simd', 0)
+        cyc = max(rec['finalize_valu_busy_cycles_per_simd'] + 10.0 * n_mfma, 32.6 * n_mfma)
+        fl = cyc / (fin_clock['mhz_median_under_load'] * 1e3)
+        fin_issue.update(valu_busy_cycles_per_simd=rec['finalize_valu_busy_cycles_per_simd'],
+                         mfma_insts_per_simd=n_mfma, mfma_issue_block_cycles=10, mfma_pipe_cycles_each=32.6,
+                         model='max(VALU busy + 10 cycles of closed VALU port per MFMA, MFMA count x 32.6 cycles of matrix pipe) per SIMD '
+                               '(tools/ubench_issue.hip); the class kernels only -- the timed launch also holds the table upload + zeroing kernel',
+                         floor_ms=round(fl, 4), frac=round(fl / fin_ms, 4), source=prof_note, counters_measured_in_run=False)
+    out['fin_ms'] = fin_ms
+    out['roofline_finalize'] = dict(bound='hbm', kernel=fin_kernel, achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
+                                    unit='GB/s', frac=round(fin_gbs / HBM_PEAK_GBS, 4), bytes_per_launch=int(fin_bytes),
+                                    ms_per_launch=round(fin_ms, 4), traffic=rec.get('finalize_bytes_per_launch') if rec else None,
+                                    traffic_measured_in_run=False)
+    out['roofline_finalize_issue'] = fin_issue
+    eng.close()
+    del sets, calls
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50, help='timed generations per rank')
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='sdxl1024', choices=sorted(WORKLOADS))
-    ap.add_argument('--denoise-steps', type=int, default=50)
+    ap.add_argument('--denoise-steps', type=int, default=0, help='denoising steps per generation (0 = the configuration\'s: 50; SDXL-2048: 100)')
     ap.add_argument('--defer', type=int, default=int(os.environ.get('DAAM_DEFER_STEPS', '64')),
                     help='denoising steps tapped per launch (0 = one launch per layer call)')
+    ap.add_argument('--defer-bytes', type=int, default=int(os.environ.get('DAAM_DEFER_BYTES', '0')),
+                    help='bytes of recorded Q / K per launch (0 = 40 %% of the device memory, the rule daam_amd.trace applies)')
     ap.add_argument('--accumulate', default='exact', choices=['exact', 'float32'])
     ap.add_argument('--pool', type=int, default=0,
                     help='distinct synthetic Q/K step sets resident in HBM (0 = one per denoising step: no step of a '
-                         'generation re-reads data an earlier one left in L2 / Infinity Cache)')
+                         'generation re-reads data an earlier one left in L2 / Infinity Cache; SDXL-2048: 25 sets = 39 GB)')
     ap.add_argument('--no-baselines', action='store_true', help='skip the CPU / eager-GPU reference timings')
     ap.add_argument('--no-integrated', action='store_true', help='skip the integrated-overhead leg')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the short legs of the other single-GPU BASELINE configurations')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='process-group backend of a multi-rank run: nccl = RCCL over xGMI (production); gloo = functional runs')
+    ap.add_argument('--shared-device', action='store_true',
+                    help='functional test of the multi-rank path on a one-GPU box: every rank uses cuda:0 (needs --dist-backend gloo: '
+                         'RCCL refuses two ranks on one device); the line says so and is not a scaling measurement')
     args = ap.parse_args()
+    if args.shared_device and args.dist_backend != 'gloo':
+        raise SystemExit('--shared-device needs --dist-backend gloo (RCCL refuses a duplicate GPU)')
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        _respawn_under_launcher(args.gpus)
+        _respawn_under_launcher(args.gpus, args.shared_device)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = 0 if args.shared_device else int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+    comm = Comm(args.dist_backend, device) if world > 1 else None
 
-    from daam_amd.engine import HeatMapEngine
-    wl = WORKLOADS[args.workload]
-    layers = topology(wl['kind'], wl['latent'])
-    latent_side = 64
-    pool = args.pool if args.pool > 0 else args.denoise_steps
-    sets = make_inputs(layers, pool, device, seed=1234 + rank)
-    eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=args.accumulate, defer_steps=args.defer)
-
-    calls = call_lists(layers, sets, latent_side)
-    # untimed: the W warm-up generations, plus whatever it takes to reach steady state -- the first call
-    # creates the context and loads the code objects (36 ms), the GPU needs ~10 generations from idle to its
-    # sustained clock, and the one-off costs of the result stack / the RCCL communicator are paid here too
-    warm = [one_generation(eng, calls, args.denoise_steps) for _ in range(max(args.warmup, 1))]
-    for _ in range(max(0, 20 - len(warm))):
-        one_generation(eng, calls, args.denoise_steps)
-    w = torch.stack(warm[:2])
-    if dist:
-        gathered = torch.empty(world * w.shape[0], *w.shape[1:], device=device, dtype=w.dtype)
-        dist.all_gather_into_tensor(gathered, w)
-    del warm, w
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    results = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        results.append(one_generation(eng, calls, args.denoise_steps))
-    mine = torch.stack(results)
-    if dist:
-        gathered = torch.empty(world * args.steps, *mine.shape[1:], device=device, dtype=mine.dtype)
-        dist.all_gather_into_tensor(gathered, mine)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    denoise = args.denoise_steps or WORKLOADS[args.workload].get('denoise_steps', 50)
+    main_rec = run_workload(args.workload, denoise, args.steps, args.warmup, device, args, comm=comm, rank=rank, world=world)
 
     out = None
     if rank == 0:
-        acc_bytes = 2 if args.accumulate == 'exact' else 4
-        # steps one tap launch covers: the step window, or fewer when the recorded Q / K reach the engine's
-        # byte budget (a launch is then forced at the next step boundary)
-        step_bytes = sum(q.numel() * q.element_size() + k.numel() * k.element_size() for q, k in sets[0])
-        spl = max(1, min(args.defer, args.denoise_steps, 64, -(-eng.defer_bytes // step_bytes)))
-        # ---- roofline of the dominant kernel (tap) ---------------------------------------------
-        if args.defer > 0:
-            launches_per_gen = -(-args.denoise_steps // spl)
-            fresh = launches_per_gen == 1
-            tap_ms = measure_tap_kernel(eng, calls, spl, reps=10, fresh=fresh)
-            bytes_launch, qk_bytes, acc_total = tap_bytes(layers, spl, acc_bytes, fresh=fresh)
-        else:
-            # immediate mode: 1 launch per layer call; time a whole denoising step of launches
-            stream = torch.cuda.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            one_generation(eng, calls, 2)
-            e0.record(stream)
-            reps = 10
-            for r in range(reps):
-                for a in calls[r % len(calls)]:
-                    eng.tap_qk(*a)
-            e1.record(stream)
-            e1.synchronize()
-            tap_ms = e0.elapsed_time(e1) / reps / len(layers)
-            bytes_launch, qk_bytes, acc_total = tap_bytes(layers, 1, acc_bytes, fresh=False)
-            bytes_launch /= len(layers)
-            launches_per_gen = args.denoise_steps * len(layers)
-        achieved = bytes_launch / (tap_ms * 1e-3) / 1e9
-        survey_bytes = spl * (qk_bytes + 2 * acc_total) if args.defer > 0 else bytes_launch   # RMW per step
-        key = f'{args.workload}:defer{spl}:{args.accumulate}'
-        prof, prof_note = load_profile('r02_counters.json')
-        rec = (prof or {}).get('workloads', {}).get(key)
-        traffic = rec.get('tap_bytes_per_launch') if rec else None
-        tap_kernel = ('tap_d64_kernel (16x16x32 MFMA tiles, head_dim 64)' if wl['kind'] == 'sdxl'
-                      else 'tap_d64_kernel (head_dim 40) + tap_mfma_kernel<KS=5|10> (head_dim 80 / 160) side by side')
-        roofline = dict(bound='hbm', kernel=tap_kernel,
-                        achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=traffic, traffic_source=prof_note if rec else (prof_note or 'no PMC pass committed for this workload'),
-                        bytes_per_launch=int(bytes_launch), ms_per_launch=round(tap_ms, 4),
-                        steps_per_launch=spl, launches_per_generation=launches_per_gen,
-                        achieved_at_survey_8d_bytes=round(survey_bytes / (tap_ms * 1e-3) / 1e9, 1))
-        # ---- issue-rate roofline of the same launch: the deferred tap keeps the sums in registers, so its HBM work is the
-        # Q / K stream only and the kernel is bound by instruction issue (softmax VALU + MFMA).  Floor = (VALU busy cycles +
-        # MFMA instructions x the ~10 cycles each keeps the VALU port closed, tools/ubench_issue) per SIMD / shader clock.
-        roofline_issue = None
-        if args.defer > 0:
-            mon = ClockMonitor(eng, window_ms=40.0)                  # second pass with the monitor wave running beside the kernel
-            measure_tap_kernel(eng, calls, spl, reps=8, fresh=fresh)
-            clock = mon.read()
-            roofline_issue = dict(bound='issue', kernel=tap_kernel, clock=clock, ms_per_launch=round(tap_ms, 4))
-            if rec and clock and rec.get('tap_valu_busy_cycles_per_simd'):
-                cyc = rec['tap_valu_busy_cycles_per_simd'] + 10.0 * rec.get('tap_mfma_per_simd', 0)
-                floor_ms = cyc / (clock['mhz_median_under_load'] * 1e3)
-                roofline_issue.update(valu_busy_cycles_per_simd=rec['tap_valu_busy_cycles_per_simd'],
-                                      valu_insts_per_simd=rec.get('tap_valu_insts_per_simd'),
-                                      mfma_insts_per_simd=rec.get('tap_mfma_per_simd'), mfma_issue_block_cycles=10,
-                                      floor_ms=round(floor_ms, 4), frac=round(floor_ms / tap_ms, 4), source=prof_note)
-            else:
-                roofline_issue['note'] = prof_note or 'no PMC pass committed for this workload'
-        # host cost of the per-layer call path for one generation (launches are asynchronous)
-        torch.cuda.synchronize()
-        th0 = time.perf_counter()
-        for t in range(args.denoise_steps):
-            for a in calls[t % len(calls)]:
-                eng.tap_qk(*a)
-        eng.flush()
-        host_ms = (time.perf_counter() - th0) * 1e3
-        torch.cuda.synchronize()
-        fin_ms = measure_finalize(eng, reps=40)
-        mon = ClockMonitor(eng, window_ms=10.0, period_us=50)       # the clock in a second pass: the monitor wave is kept out of the timing
-        measure_finalize(eng, reps=60)
-        fin_clock = mon.read()
-        fin_bytes = acc_total + 77 * 64 * 64 * 4
-        fin_gbs = fin_bytes / (fin_ms * 1e-3) / 1e9
-        fin_kernel = {'sdxl1024': 'table upload + zeroing, finalize_up32_same_kernel (x2 MFMA class and same-size class in one launch)',
-                      'sdxl2048': 'table upload + zeroing, finalize_down2 (128 -> 64) + finalize_same_kernel',
-                      'sd15': 'table upload + zeroing, finalize_same / finalize_up32_mfma / finalize_up_kernel<16>'}[args.workload]
-        fin_issue = dict(bound='issue', kernel=fin_kernel, clock=fin_clock, ms_per_launch=round(fin_ms, 4))
-        if rec and fin_clock and rec.get('finalize_valu_busy_cycles_per_simd'):
-            n_mfma = rec.get('finalize_mfma_per_simd', 0)
-            cyc = max(rec['finalize_valu_busy_cycles_per_simd'] + 10.0 * n_mfma, 32.6 * n_mfma)
-            fl = cyc / (fin_clock['mhz_median_under_load'] * 1e3)
-            fin_issue.update(valu_busy_cycles_per_simd=rec['finalize_valu_busy_cycles_per_simd'],
-                             mfma_insts_per_simd=n_mfma, mfma_issue_block_cycles=10, mfma_pipe_cycles_each=32.6,
-                             model='max(VALU busy + 10 cycles of closed VALU port per MFMA, MFMA count x 32.6 cycles of matrix pipe) per SIMD '
-                                   '(tools/ubench_issue.hip); the class kernels only -- the timed launch also holds the table upload + zeroing kernel',
-                             floor_ms=round(fl, 4), frac=round(fl / fin_ms, 4), source=prof_note)
-        gpu_ms_per_gen = launches_per_gen * tap_ms + fin_ms
+        r = main_rec
+        gpu_ms_per_gen = r['tap_ms_per_generation'] + r['fin_ms']
         extra = dict(
-            extraction_overhead_ms_per_denoise_step=round((elapsed / args.steps * 1e3) / args.denoise_steps, 4),
-            gpu_ms_per_denoise_step=round(launches_per_gen * tap_ms / args.denoise_steps, 4),
+            extraction_overhead_ms_per_denoise_step=round(r['ms_per_step'] / denoise, 4),
+            gpu_ms_per_denoise_step=round(r['tap_ms_per_generation'] / denoise, 4),
             gpu_bound_maps_per_s=round(1e3 / gpu_ms_per_gen, 1),
-            host_enqueue_ms_per_generation=round(host_ms, 3),
-            raw_maps_per_s=round(world * args.steps * args.denoise_steps * sum(h for _, h, _, _ in layers) / elapsed, 1),
-            roofline_finalize=dict(bound='hbm', kernel=fin_kernel, achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
-                                   unit='GB/s', frac=round(fin_gbs / HBM_PEAK_GBS, 4), bytes_per_launch=int(fin_bytes),
-                                   ms_per_launch=round(fin_ms, 4), traffic=rec.get('finalize_bytes_per_launch') if rec else None),
-            roofline_issue=roofline_issue, roofline_finalize_issue=fin_issue,
+            host_enqueue_ms_per_generation=round(r['host_ms'], 3),
+            raw_maps_per_s=round(world * args.steps * denoise * r['keys'] / r['elapsed'], 1),
+            roofline_finalize=r['roofline_finalize'], roofline_issue=r['roofline_issue'],
+            roofline_finalize_issue=r['roofline_finalize_issue'],
         )
-        eng.close()
-        del sets
-        torch.cuda.empty_cache()
+        if world == 1 and not args.no_other_configs and args.workload == 'sdxl1024':
+            # the other single-GPU configurations of BASELINE.json, short legs (their parity: tests/test_gpu_integration.py)
+            others = {}
+            for name, g, wu in (('sd15', 20, 5), ('sdxl2048', 5, 2)):
+                ds = WORKLOADS[name].get('denoise_steps', 50)
+                o = run_workload(name, ds, g, wu, device, args, detail=False)
+                others[name] = dict(config=f'{o["label"]}, {ds} denoising steps, 77 tokens, CFG batch 2, fp16 Q/K',
+                                    value=round(o['value'], 2), unit='maps/s', generations=g, warmup=wu,
+                                    ms_per_step=round(o['ms_per_step'], 3),
+                                    gpu_bound_maps_per_s=round(1e3 / (o['tap_ms_per_generation'] + o['fin_ms']), 1),
+                                    roofline=o['roofline'], roofline_issue=o['roofline_issue'],
+                                    roofline_finalize=o['roofline_finalize'])
+            extra['other_configs'] = others
         if not args.no_integrated and world == 1 and args.workload == 'sdxl1024':
             extra['integrated'] = integrated_overhead(device)
             # the processor's attention on daam_attend (tools/attend_bench.py): per denoising step of 60 layer calls, next
@@ -544,26 +665,29 @@ def main():
             extra['attend'] = attend_measure(steps=20, reps=3, dev=device)
         cpu = None
         if not args.no_baselines and world == 1:
-            cpu = cpu_baseline(wl['kind'], wl['latent'], args.denoise_steps, eager_device=device)
+            wl = WORKLOADS[args.workload]
+            cpu = cpu_baseline(wl['kind'], wl['latent'], denoise, eager_device=device)
             ref_gpu = cpu.pop('eager_mi355x')
             extra['reference_eager_mi355x'] = {k: round(v, 4) for k, v in ref_gpu.items()}
-            extra['speedup_vs_eager_mi355x'] = round((world * args.steps / elapsed) / ref_gpu['maps_per_s'], 1)
-            cpu = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in cpu.items()}
+            extra['speedup_vs_eager_mi355x'] = round(r['value'] / ref_gpu['maps_per_s'], 1)
+            cpu = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in cpu.items()}
         out = {
-            'metric': 'heat maps/sec, DAAM extraction (tap + compute_global_heat_map), ' + wl['label'] +
-                      f', {args.denoise_steps}-step, 77-tok',
-            'value': round(world * args.steps / elapsed, 2), 'unit': 'maps/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'metric': 'heat maps/sec, DAAM extraction (tap + compute_global_heat_map), ' + r['label'] +
+                      f', {denoise}-step, 77-tok',
+            'value': round(r['value'], 2), 'unit': 'maps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(r['ms_per_step'], 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-            'config': {'workload': f'{wl["label"]}, {args.denoise_steps} denoising steps, 77 tokens, CFG batch 2, fp16 Q/K',
-                       'accumulate': args.accumulate, 'defer_steps': spl, 'parallelism': f'prompt-shard x{world}',
-                       'generations_per_rank': args.steps},
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'config': {'workload': f'{r["label"]}, {denoise} denoising steps, 77 tokens, CFG batch 2, fp16 Q/K',
+                       'accumulate': args.accumulate, 'defer_steps': r['steps_per_launch'], 'parallelism': f'prompt-shard x{world}',
+                       'generations_per_rank': args.steps,
+                       'collective': None if world == 1 else f'all_gather of the final [{args.steps}, 77, 64, 64] fp32 maps per rank over '
+                                                              f'{args.dist_backend}' + (' -- ALL RANKS ON ONE DEVICE (functional run, not a '
+                                                                                        'scaling measurement)' if args.shared_device else '')},
+            'roofline': r['roofline'], 'cpu_baseline': cpu,
         }
         out.update(extra)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm:
+        comm.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
 

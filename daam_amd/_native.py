@@ -13,16 +13,16 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32,
 LIB_NAME = 'libdaam_hip.so'
 LIB_PATH = os.environ.get('DAAM_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DAAM_F16, DAAM_F32, DAAM_BF16 = 0, 1, 2
 E_INVALID, E_STATE, E_NOMAPS, E_UNSUPPORTED = -1, -2, -3, -4
 
 # every symbol include/daam_hip.h declares (tests check the library exports exactly these)
 EXPORTS = (
     'daam_abi_version', 'daam_last_error', 'daam_ctx_create', 'daam_ctx_destroy', 'daam_layer_configure',
-    'daam_layer_acc', 'daam_layer_touch', 'daam_reset', 'daam_tap_qk', 'daam_tap_qk_enqueue', 'daam_tap_qk_enqueue_many', 'daam_tap_pending', 'daam_tap_flush',
+    'daam_layer_acc', 'daam_layer_touch', 'daam_layer_release', 'daam_reset', 'daam_tap_qk', 'daam_tap_qk_enqueue', 'daam_tap_qk_enqueue_many', 'daam_tap_pending', 'daam_tap_flush',
     'daam_tap_probs', 'daam_attend_supported', 'daam_attend', 'daam_key_offset', 'daam_finalize', 'daam_epilogue_normalize', 'daam_word_heat_map', 'daam_mask_overlap',
-    'daam_last_launch', 'daam_profile_enable', 'daam_profile_last_ms', 'daam_clock_monitor_start', 'daam_clock_monitor_read',
+    'daam_last_launch', 'daam_last_flush', 'daam_profile_enable', 'daam_profile_last_ms', 'daam_clock_monitor_start', 'daam_clock_monitor_read',
 )
 
 
@@ -70,6 +70,7 @@ def load() -> ctypes.CDLL:
     lib.daam_layer_configure.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.daam_layer_acc.argtypes = [c_void_p, c_int, POINTER(c_void_p), POINTER(c_size_t)]
     lib.daam_layer_touch.argtypes = [c_void_p, c_int, c_void_p]
+    lib.daam_layer_release.argtypes = [c_void_p, c_int]
     lib.daam_reset.argtypes = [c_void_p, c_void_p]
     lib.daam_tap_qk.argtypes = [c_void_p, c_int, c_void_p, c_void_p, POINTER(QKDesc), c_void_p]
     lib.daam_tap_qk_enqueue.argtypes = [c_void_p, c_int, c_void_p, c_void_p, POINTER(QKDesc)]
@@ -86,6 +87,7 @@ def load() -> ctypes.CDLL:
                                        c_int, c_float, c_void_p, c_void_p]
     lib.daam_mask_overlap.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.daam_last_launch.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
+    lib.daam_last_flush.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(ctypes.c_longlong)]
     lib.daam_profile_enable.argtypes = [c_void_p, c_int]
     lib.daam_profile_last_ms.argtypes = [c_void_p, c_int, POINTER(c_float)]
     lib.daam_clock_monitor_start.argtypes = [c_void_p, c_int, c_int]

@@ -193,6 +193,8 @@ struct DaamCtx {
     std::vector<int> pending_last;    // per layer: index of its newest entry in `pending`
     void drop_pending() { pending.clear(); pending_count.clear(); pending_last.clear(); }
     int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
+    int last_flush_kernels = 0, last_flush_side = 0, last_flush_steps = 0;   // daam_last_flush: kernels / of them on side streams / longest step chain
+    long long n_flushes = 0;           // tap launches (flushes that launched something) since the context was created
     int profile = 0;
     hipEvent_t prof_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     // shader-clock monitor (daam_clock_monitor_*): one wave on its own stream samples the shader-cycle counter and the
@@ -457,6 +459,20 @@ int daam_layer_touch(DaamCtx* c, int layer, void* stream)
     int zrc = ensure_zeroed(l, (hipStream_t)stream);       // a reset still owed to the buffer happens first, on this stream
     if (zrc) return zrc;
     l.dirty = true;                                        // later taps add to the sums, the next reset clears them
+    return 0;
+}
+
+int daam_layer_release(DaamCtx* c, int layer)
+{
+    if (!c || layer < 0 || layer >= c->max_layers) return fail(DAAM_E_INVALID, "layer %d out of range", layer);
+    for (auto& p : c->pending)
+        if (p.layer == layer) return fail(DAAM_E_STATE, "layer %d released with un-flushed taps pending", layer);
+    Layer& l = c->layers[layer];
+    if (l.owned && l.acc) {
+        DeviceGuard on_device(c);
+        HIP_TRY(hipFree(l.acc));
+    }
+    l = Layer();                                               // unconfigured: no later call touches the old buffer
     return 0;
 }
 
@@ -851,6 +867,11 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     if (c->profile && ev_started) (void)hipEventRecord(c->prof_ev[0][1], s);
     c->last_grid[0] = grid_total;
     c->last_block[0] = 256;
+    c->last_flush_kernels = (int)launch_order.size();
+    c->last_flush_side = n_side;
+    c->last_flush_steps = 0;
+    for (auto& v : per) c->last_flush_steps = std::max(c->last_flush_steps, (int)v.size());
+    ++c->n_flushes;
     c->drop_pending();
     return rc;
 }
@@ -956,6 +977,16 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     c->last_grid[1] = 0;
     c->last_lds[1] = 0;
     static const int env_chunks = getenv("DAAM_FIN_CHUNKS") ? atoi(getenv("DAAM_FIN_CHUNKS")) : 0;
+    // x2 class on the matrix cores (fp16 planes, fp16-exact tap matrix)?  Decided BEFORE the chunking: that kernel walks a
+    // host-built chunk table of at most kFinMaxChunks chunks x 2 key lanes x 64 keys, so a larger class goes out as several
+    // launches over key sub-ranges (kFinMfmaKeysPerLaunch each) -- the LDS kernel and the other classes take any key count.
+    constexpr int kFinMfmaKeysPerLaunch = kFinMaxChunks * 128;
+    const bool mfma_up = !keys[1].empty() && c->acc_dtype == DAAM_F16 && keys[1][0].tab == c->up32_tab && c->d_up32_ops &&
+                         c->tab_fp16_exact[keys[1][0].tab] && !c->no_mfma_finalize;
+    // x2 class chunking: ~1000 workgroups (one full round at 4 workgroups per CU) measured best -- fewer leaves a ragged
+    // tail, more pays the per-workgroup reduction + atomics too often; every key lane of a chunk takes at most 64 keys
+    const int want_up = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
+    auto up_chunks = [&](int n) { return std::max(std::max(1, std::min((n + 3) / 4, want_up)), (n + 127) / 128); };
     // build the launch descriptor of every non-empty class first
     FinLaunch launches[kClasses];
     bool have[kClasses] = {false, false, false, false, false};
@@ -973,7 +1004,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         L.out_side = c->out_side;
         L.inv_n = 1.0f / (float)total;
         L.max_side = max_side;
-        L.mfma_ops = (cls == 1 && keys[cls][0].tab == c->up32_tab) ? c->d_up32_ops : nullptr;
+        L.mfma_ops = (cls == 1 && mfma_up) ? c->d_up32_ops : nullptr;
         if (cls == 0) {
             // 154 workgroups per chunk: 4 chunks for the 100 same-size keys of SDXL-1024, up to 16 (2464 workgroups, ~2.4 rounds)
             // for the 1000 of SDXL-2048 -- a pure HBM stream wants every CU's queues full
@@ -981,22 +1012,29 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         } else if (cls == 3) {
             L.n_chunks = std::max(1, std::min(n, 32));
         } else {
-            // each wave takes keys first, first + 4*n_chunks, ...: at most 64 per wave.  ~1000 workgroups
-            // (one full round at 4 workgroups per CU) measured best: fewer leaves a ragged tail,
-            // more pays the per-workgroup reduction + atomics too often.
-            const int want = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
-            L.n_chunks = std::max(std::max(1, std::min((n + 3) / 4, want)), (n + 127) / 128);   // <= 64 keys per wave (2 or 4 key lanes per workgroup)
-            if (cls == 1) L.n_chunks = std::min(L.n_chunks, kFinMaxChunks);
+            // each wave takes keys first, first + 4*n_chunks, ...: at most 64 per wave (4 key lanes per workgroup; the MFMA
+            // kernel of class 1 has 2 and is chunked per launch below)
+            L.n_chunks = up_chunks(n);
         }
         memset(L.chunk_begin, 0, sizeof L.chunk_begin);
-        if (cls == 1) finalize_chunk_ranges(n, L.n_chunks, &L);
         have[cls] = true;
     }
-    const bool mfma_up = have[1] && c->acc_dtype == DAAM_F16 && launches[1].mfma_ops &&
-                         c->tab_fp16_exact[keys[1][0].tab] && !c->no_mfma_finalize &&
-                         (int)keys[1].size() <= kFinMaxChunks * 128;          // chunk table of the MFMA kernel: 31 chunks x 2 x 64 keys
+    // the MFMA kernel's launches: key sub-ranges of at most kFinMfmaKeysPerLaunch keys, each with its own chunk table
+    std::vector<FinLaunch> up_parts;
+    if (mfma_up) {
+        const FinLaunch& U = launches[1];
+        for (int begin = 0; begin < U.n_keys; begin += kFinMfmaKeysPerLaunch) {
+            FinLaunch P = U;
+            P.keys = U.keys + begin;
+            P.n_keys = std::min(kFinMfmaKeysPerLaunch, U.n_keys - begin);
+            P.n_chunks = std::min(up_chunks(P.n_keys), kFinMaxChunks);
+            finalize_chunk_ranges(P.n_keys, P.n_chunks, &P);
+            up_parts.push_back(P);
+        }
+        launches[1] = up_parts[0];                             // what the paired launch takes (single part)
+    }
     // SDXL-1024 in fp16: the same-size and the x2 class side by side in ONE launch
-    const bool paired = mfma_up && have[0] && !c->no_paired_finalize;
+    const bool paired = mfma_up && up_parts.size() == 1 && have[0] && !c->no_paired_finalize;
     // the output is accumulated with atomics: zero it in the table-upload launch
     const bool zero_in_upload = out_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
     if (!zero_in_upload) {
@@ -1017,10 +1055,18 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         int grid = 0, lds = 0;
         hipError_t e;
         if (cls == 1 && paired) e = launch_finalize_up32_same(L, launches[0], s, &grid);
+        else if (cls == 1 && mfma_up) {
+            e = hipSuccess;
+            for (size_t part = 0; part < up_parts.size() && e == hipSuccess; ++part) {
+                int g = 0;
+                e = launch_finalize_up(up_parts[part], 32, c->acc_dtype, 1, s, &g);
+                grid += g;
+            }
+        }
         else if (cls == 0) e = launch_finalize_same(L, c->acc_dtype, s, &grid);
         else if (cls == 3) e = launch_finalize(L, c->acc_dtype, s, &grid, &lds);
         else if (cls == 4) e = launch_finalize_down2(L, c->acc_dtype, s, &grid);
-        else e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, c->tab_fp16_exact[keys[cls][0].tab] && !c->no_mfma_finalize, s, &grid);
+        else e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, 0, s, &grid);
         if (e != hipSuccess) {
             (void)c->ring.release(s);                      // the table region is reusable once whatever did launch has run
             return fail((int)e, "finalize launch (class %d): %s", cls, hipGetErrorString(e));
@@ -1115,6 +1161,16 @@ int daam_clock_monitor_read(DaamCtx* c, float* mhz, int capacity, int* n_interva
         if (b[1] > a[1] && b[0] > a[0]) mhz[n++] = (float)((double)(b[0] - a[0]) / (double)(b[1] - a[1]) * 100.0);   // reference: 100 MHz
     }
     *n_intervals = n;
+    return 0;
+}
+
+int daam_last_flush(DaamCtx* c, int* n_kernels, int* n_side_streams, int* max_steps, long long* n_flushes)
+{
+    if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
+    if (n_kernels) *n_kernels = c->last_flush_kernels;
+    if (n_side_streams) *n_side_streams = c->last_flush_side;
+    if (max_steps) *max_steps = c->last_flush_steps;
+    if (n_flushes) *n_flushes = c->n_flushes;
     return 0;
 }
 

@@ -339,7 +339,7 @@ PyObject* Recorder_attend(Recorder* self, PyObject* const* args, Py_ssize_t narg
                          static_cast<int>(dev.type()) == a.device_type && static_cast<int>(dev.index()) == a.device &&
                          k.device() == dev && v.device() == dev && heads == a.heads && scale == a.scale && rl == a.round_logits &&
                          q.is_contiguous() && k.is_contiguous() && v.is_contiguous() && q.has_storage() &&
-                         !(q.requires_grad() && c10::GradMode::is_enabled());
+                         !((q.requires_grad() || k.requires_grad() || v.requires_grad()) && c10::GradMode::is_enabled());
                 if (steady) {
                     out = at::empty_like(q);
                     void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();

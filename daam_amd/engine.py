@@ -258,7 +258,13 @@ class HeatMapEngine:
             nat.check(self.lib.daam_reset(self.ctx, self.stream))
         if self._views_out:
             # the reference's clear() drops its dict and the tensors it handed out live on unchanged
-            # (heatmap.py:170-172): leave the old buffers to those views and start the next generation on new ones
+            # (heatmap.py:170-172): leave the old buffers to those views and start the next generation on new ones.
+            # The native context must forget them too -- daam_reset only marked them "to be zeroed", and a layer
+            # that is not tapped again (another resolution turns its factor into 8) would otherwise be zeroed by the
+            # next finalize: a write into memory the views own, or that is back in the caching allocator.
+            if self.ctx is not None:
+                for layer in list(self.layer_info):
+                    nat.check(self.lib.daam_layer_release(self.ctx, layer))
             self.acc, self.layer_info = {}, {}
             self._qk_cache = [None] * self.n_layers
             self._att_cache = [None] * self.n_layers
@@ -328,6 +334,16 @@ class HeatMapEngine:
         """Recorded taps that have not been launched yet."""
         return self._fast.count() if self._fast is not None else len(self._rec)
 
+    def last_flush(self) -> dict:
+        """Launch structure of the last deferred tap launch (``daam_last_flush``): kernels launched, how many of them ran on
+        auxiliary streams beside the caller's, the longest per-layer step chain, and the number of tap launches this
+        context has made so far."""
+        if self.ctx is None:
+            return dict(kernels=0, side_streams=0, max_steps=0, launches=0)
+        k, sd, ms, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+        nat.check(self.lib.daam_last_flush(self.ctx, ctypes.byref(k), ctypes.byref(sd), ctypes.byref(ms), ctypes.byref(n)))
+        return dict(kernels=k.value, side_streams=sd.value, max_steps=ms.value, launches=n.value)
+
     def _pending(self, layer: int) -> int:
         return self._fast.pending(layer) if self._fast is not None else self._cnt[layer]
 
@@ -390,8 +406,8 @@ class HeatMapEngine:
             a = self._prepare_attend(layer, query, key, value, heads, scale, round_logits)
         if (a[6] is None or value.shape != a[1] or key.dtype is not a[2] or value.dtype is not a[2]
                 or not (query.is_contiguous() and key.is_contiguous() and value.is_contiguous())
-                or (query.requires_grad and torch.is_grad_enabled())):     # the kernel has no backward: leave autograd to torch
-            return None
+                or ((query.requires_grad or key.requires_grad or value.requires_grad) and torch.is_grad_enabled())):
+            return None                                                    # the kernel has no backward: leave autograd to torch
         fused_tap = tapped and not self.defer_steps
         if fused_tap:
             c = self._qk_cache[layer]

@@ -17,9 +17,14 @@ from . import _native as nat
 __all__ = ['compute_iou', 'compute_ioa', 'mask_overlap', 'compute_iou_batch', 'compute_ioa_batch']
 
 
-def _as_batch(t: torch.Tensor, name: str) -> torch.Tensor:
+def _as_batch(t: torch.Tensor, name: str, device=None) -> torch.Tensor:
     if t.device.type != 'cuda':
-        raise RuntimeError(f'daam_amd: {name} must live on the HIP device (no CPU fallback)')
+        # the reference's evaluation flow hands over CPU masks (load_mask, and expand_as ends in .cpu()): they are moved
+        # to the HIP device (the other operand's, else the current one) -- the arithmetic still runs there and only
+        # there, and a box without an MI355X fails right here
+        if not torch.cuda.is_available():
+            raise RuntimeError(f'daam_amd: {name} is a CPU tensor and no HIP device is visible (there is no CPU fallback)')
+        t = t.to(device if device is not None else torch.device('cuda', torch.cuda.current_device()))
     if t.dim() == 2:
         t = t.unsqueeze(0)
     if t.dim() != 3:
@@ -31,7 +36,8 @@ def mask_overlap(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """``a`` [n, ah, aw] (or [ah, aw]) predictions, ``b`` [n, bh, bw] truths -> ``[n, 3]`` fp32 = (sum(a*b), sum(a), sum(b))
     with the reference's preprocessing of ``a``: if ``a.shape[0] != b.shape[0]`` (per pair: the HEIGHTS differ,
     evaluate.py:15) bicubic-resize to ``b``'s size and binarise at 1."""
-    a, b = _as_batch(a, 'a'), _as_batch(b, 'b')
+    dev = a.device if a.device.type == 'cuda' else (b.device if b.device.type == 'cuda' else None)
+    a, b = _as_batch(a, 'a', dev), _as_batch(b, 'b', dev)
     if a.shape[0] != b.shape[0]:
         raise ValueError(f'{a.shape[0]} predictions for {b.shape[0]} truth masks')
     if a.device != b.device:

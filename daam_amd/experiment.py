@@ -11,6 +11,7 @@ are not rebuilt."""
 from __future__ import annotations
 
 import json
+import warnings
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Any, Dict, Optional, Union
@@ -100,8 +101,11 @@ class GenerationExperiment:
         for word in self.prompt.split(' '):
             try:
                 out[word] = self.save_heat_map(word, tokenizer, crop=crop)
-            except ValueError:         # "Search word ... not found in prompt!": skipped, like the reference (experiment.py:250-255)
-                pass
+            except Exception as exc:   # noqa: BLE001 -- the reference skips a word on ANY failure (bare except, experiment.py:250-255)
+                # "Search word ... not found in prompt!" is the expected one; anything else is skipped too (one bad word must
+                # not abort save()), but said out loud
+                if not isinstance(exc, ValueError):
+                    warnings.warn(f'daam_amd: heat map of {word!r} skipped: {type(exc).__name__}: {exc}')
         return out
 
     @staticmethod

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DAAM_ABI_VERSION 3
+#define DAAM_ABI_VERSION 4
 
 /* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
 #define DAAM_API __attribute__((visibility("default")))
@@ -97,6 +97,11 @@ DAAM_API int daam_layer_acc(DaamCtx* ctx, int layer, void** acc, size_t* bytes);
  * heatmap.py:153-156): a zeroing still owed to the buffer since the last daam_reset is enqueued on `stream` first,
  * and the layer counts as holding sums (the next tap adds to them, the next daam_reset clears them). */
 DAAM_API int daam_layer_touch(DaamCtx* ctx, int layer, void* stream);
+/* Forget layer `layer`: the context drops its pointer to the sums (a library-owned buffer is freed) and never touches that
+ * memory again -- not even for a zeroing still owed since daam_reset.  This is RawHeatMapCollection.clear()
+ * (daam/heatmap.py:170-172) as seen from tensors the caller handed out before: the reference drops its dict and the old
+ * tensors live on unchanged.  The layer must be configured again before its next tap.  DAAM_E_STATE with taps pending. */
+DAAM_API int daam_layer_release(DaamCtx* ctx, int layer);
 
 /* RawHeatMapCollection.clear (heatmap.py:170-172; called from check_inputs, trace.py:179):
  * zero every running sum and drop any un-flushed deferred taps. */
@@ -185,6 +190,11 @@ DAAM_API const char* daam_last_error(void);
 /* per-kernel launch statistics of the last tap / finalize launch (for bench.py):
  * grid size and dynamic LDS bytes; 0 if nothing launched yet. */
 DAAM_API int daam_last_launch(DaamCtx* ctx, int which /*0 tap,1 finalize*/, int* grid, int* block, int* lds_bytes);
+/* launch structure of the last daam_tap_flush that launched something: kernels launched (one per kernel kind: SD-v1.5 has
+ * head_dim 40 / 80 / 160 = three), how many of them went to auxiliary streams beside the caller's, the longest per-layer
+ * step chain of the launch; `n_flushes` counts such flushes since daam_ctx_create (tests and bench.py assert the launch
+ * structure a configuration is supposed to have: launches per generation, side-by-side kernels). Any pointer may be NULL. */
+DAAM_API int daam_last_flush(DaamCtx* ctx, int* n_kernels, int* n_side_streams, int* max_steps, long long* n_flushes);
 /* kernel timing for bench.py: when enabled, every tap / finalize call brackets ITS KERNEL LAUNCHES (not
  * the table upload before them) with HIP events on the call's stream; daam_profile_last_ms waits for the
  * last pair and returns the elapsed milliseconds (the only other call that synchronises the host). */

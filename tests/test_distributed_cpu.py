@@ -58,3 +58,31 @@ def test_gather_single_process_passthrough():
     assert gather_heat_maps(x, 3) is x
     with pytest.raises(ValueError):
         gather_heat_maps(x, 4)
+
+
+def _comm_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    comm = bench.Comm('gloo', torch.device('cpu'))
+    try:
+        assert (comm.world, comm.rank) == (world, rank)
+        mine = torch.full((3, 2, 4, 4), float(rank)) + torch.arange(3).view(3, 1, 1, 1) / 10
+        comm.barrier()
+        got = comm.all_gather(mine)                        # rank-major: rank r's maps are rows [3r, 3r + 3)
+        assert torch.equal(got[rank * 3:(rank + 1) * 3], mine)
+        slowest = comm.max(1.0 + rank)
+        torch.save(dict(got=got, slowest=slowest), os.path.join(out_dir, f'c{rank}.pt'))
+    finally:
+        comm.close()
+
+
+def test_bench_comm_world2_gloo(tmp_path):
+    """bench.py's collective layer (barrier, all_gather of the final maps, MAX of the elapsed times) with two ranks."""
+    world = 2
+    mp.spawn(_comm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = torch.cat([torch.full((3, 2, 4, 4), float(r)) + torch.arange(3).view(3, 1, 1, 1) / 10 for r in range(world)])
+    for r in range(world):
+        rec = torch.load(os.path.join(str(tmp_path), f'c{r}.pt'))
+        assert torch.equal(rec['got'], want) and rec['slowest'] == 2.0

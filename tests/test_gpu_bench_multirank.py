@@ -1,0 +1,47 @@
+"""bench.py's multi-rank branch on the ONE-GPU box: ``python bench.py --gpus 2 --dist-backend gloo --shared-device`` re-executes
+itself under ``torch.distributed.run`` with two ranks that both drive the HIP path on cuda:0 (RCCL refuses two ranks on one
+device, so the three collectives -- barrier, all_gather of the final maps, MAX of the elapsed times -- go over gloo).  What
+runs here is everything the driver's 8-GPU launch runs except the RCCL transport itself: the respawn, the process-group
+initialisation, rank-seeded inputs, the timed all_gather inside the barriers, the MAX all-reduce, every rank checking its
+slice of the gathered maps, rank 0 printing ONE JSON line.  Run with ``-m gpu`` on an MI355X."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ['--steps', '3', '--warmup', '1', '--no-baselines', '--no-integrated', '--no-other-configs']
+
+
+def _bench(*extra, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *COMMON, *extra], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]                   # rank 0 prints, nobody else does
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_one_device():
+    one = _bench()
+    two = _bench('--gpus', '2', '--dist-backend', 'gloo', '--shared-device')
+    assert one['n_gpus'] == 1 and two['n_gpus'] == 2
+    assert two['steps'] == 3 and two['scaling'] == 'weak' and two['metric'] == one['metric']
+    assert 'ONE DEVICE' in two['config']['collective'] and 'gloo' in two['config']['collective']
+    assert two['config']['parallelism'] == 'prompt-shard x2'
+    # two ranks share one GPU: the aggregate rate is about the single-rank rate (never the 2x of two devices), minus the
+    # host-staged gather of 2 x 3 maps inside the timed region
+    assert 0.3 * one['value'] <= two['value'] <= 1.5 * one['value'], (one['value'], two['value'])
+    assert two['roofline']['launches_per_generation'] == 1 and two['roofline']['frac'] > 0.1
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *COMMON, '--gpus', str(n)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and 'refusing' in (p.stderr + p.stdout)

@@ -233,6 +233,63 @@ def test_finalize_vs_oracle(sides, acc, path, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize('n_keys,path', [(4800, 'default'), (8100, 'default'), (8100, 'no_mfma')])
+def test_finalize_many_x2_keys(n_keys, path, monkeypatch):
+    """More 32 x 32 keys than ONE launch of a x2 kernel covers (the MFMA kernel: 31 chunks x 2 key lanes x 64 = 3968; SDXL-1024
+    with num_images_per_prompt = 4 has 60 layers x 80 kept heads = 4800): the class is split over several launches, no key
+    is dropped.  Key i holds plane set (i mod 81) scaled by 2^-(i div 81 mod 4): bicubic and clamp are positively
+    homogeneous, so the expected mean follows from 81 oracle maps -- and dropping ANY subset of keys changes it."""
+    monkeypatch.setenv('DAAM_NO_MFMA_FINALIZE', '1' if path == 'no_mfma' else '0')
+    rng = np.random.default_rng(n_keys)
+    base_n, side = 81, 32
+    base = (rng.standard_normal((base_n, side * side, 77)) * 3).astype(np.float16)         # signed: the clamp matters
+    per_key = np.stack([ho.global_heat_map([((2, 0, 0), ho.unravel(np.concatenate([base[i:i + 1]] * 2))[0])], 4096)
+                        for i in range(base_n)]).astype(np.float64)                        # [81, 77, 64, 64]
+    scales = 2.0 ** -((np.arange(n_keys) // base_n) % 4)
+    want = np.zeros_like(per_key[0])
+    for i in range(n_keys):
+        want += scales[i] * per_key[i % base_n]
+    want /= n_keys
+    eng = _engine(n_layers=1, accumulate='exact')
+    bd = torch.from_numpy(base).to(DEV)
+    idx = torch.arange(n_keys, device=DEV)
+    planes = bd[idx % base_n] * torch.from_numpy(scales.astype(np.float16)).to(DEV)[:, None, None]   # exact: powers of two
+    probs = torch.cat([torch.zeros_like(planes), planes])                                  # [2 n_keys, hw, 77], cond half kept
+    del planes
+    eng.tap_probs(0, probs, factor=2)
+    del probs
+    got = eng.global_heat_map().cpu().numpy()
+    assert np.abs(got - want).max() <= 3e-6 * max(1.0, np.abs(want).max())
+    sel = eng.global_heat_map(head_idx=n_keys - 1).cpu().numpy()                           # the last key alone
+    np.testing.assert_allclose(sel, scales[-1] * per_key[(n_keys - 1) % base_n], rtol=0, atol=3e-6 * np.abs(per_key).max())
+    eng.close()
+
+
+def test_views_survive_clear_and_next_generation():
+    """``all_heat_maps`` hands out views of the live sums; like the reference's tensors (heatmap.py:170-172: clear() drops the
+    dict, tensors handed out before live on) they must keep their values through clear() AND through the next
+    generation's finalize -- also for a layer the next generation does not tap (the native context kept the
+    old buffer and zeroed it)."""
+    rng = np.random.default_rng(5)
+    eng = _engine(n_layers=2, accumulate='exact', defer_steps=4)
+    q, k = _qk(rng, 2, 2, 32 * 32, 64, np.float16)
+    qd, kd = _dev(q), _dev(k)
+    for layer in (0, 1):
+        eng.tap_qk(layer, qd, kd, 2, 0.125, factor=2)
+    views = {key: v for key, v in eng.items()}
+    before = {key: v.clone() for key, v in views.items()}
+    assert len(views) == 4 and all(float(v.sum()) > 0 for v in views.values())
+    eng.clear()
+    eng.tap_qk(0, qd, kd, 2, 0.125, factor=2)                  # generation 2 taps layer 0 only
+    assert [key for key, _ in eng.items()] == [(2, 0, 0), (2, 0, 1)]
+    gm = eng.global_heat_map()
+    torch.cuda.synchronize()
+    for key, v in views.items():
+        assert torch.equal(v, before[key]), key                # neither overwritten nor zeroed
+    assert float(gm.sum()) > 0
+    eng.close()
+
+
 def test_normalize_and_word_maps():
     rng = np.random.default_rng(5)
     maps = np.abs(rng.standard_normal((9, 64, 64))).astype(np.float32)
