@@ -43,6 +43,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """Progress on stderr (the one JSON line on stdout is the result): which leg runs, since when."""
+    print(f'[bench {time.perf_counter() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
 
 WORKLOADS = {
@@ -237,7 +245,10 @@ def cpu_baseline(kind, latent, denoise_steps, sample_steps=2, eager_device=None)
             cache[(heads, side)] = torch.rand(2 * heads, side * side, 77)
     all_threads = os.cpu_count() or torch.get_num_threads()
     counts = sorted({1, _physical_cores(), all_threads})
-    runs = [_port_sample(th, layers, denoise_steps, n, sample_steps, cache) for n in counts]
+    runs = []
+    for n in counts:
+        note(f'cpu baseline at {n} threads')
+        runs.append(_port_sample(th, layers, denoise_steps, n, sample_steps, cache))
     best = max(runs, key=lambda r: r['value'])
     out = dict(value=best['value'], unit='maps/s', cores=best['cores'], kind='port', cpu=cpu_model(),
                ms_per_denoise_step=best['ms_per_denoise_step'], finalize_s=best['finalize_s'],
@@ -418,6 +429,7 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     JSON line (rank 0) or None."""
     from daam_amd.engine import HeatMapEngine
     wl = WORKLOADS[name]
+    note(f'{name}: inputs')
     layers = topology(wl['kind'], wl['latent'])
     latent_side = 64
     pool = args.pool if args.pool > 0 else min(denoise_steps, wl.get('pool_cap', denoise_steps))
@@ -429,6 +441,7 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     # untimed: the W warm-up generations, plus whatever it takes to reach steady state -- the first call
     # creates the context and loads the code objects (36 ms), the GPU needs ~10 generations from idle to its
     # sustained clock, and the one-off costs of the result stack / the RCCL communicator are paid here too
+    note(f'{name}: warm-up')
     warm = [one_generation(eng, calls, denoise_steps) for _ in range(max(warmup, 1))]
     for _ in range(max(0, wl.get('min_warm', 20) - len(warm))):
         one_generation(eng, calls, denoise_steps)
@@ -441,6 +454,7 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     if comm:
         comm.barrier()
     torch.cuda.synchronize()
+    note(f'{name}: timed region, {gens} generations')
     results = []
     t0 = time.perf_counter()
     for _ in range(gens):
@@ -466,6 +480,7 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
         eng.close()
         return None
 
+    note(f'{name}: {world * gens / elapsed:.1f} maps/s; kernel measurements')
     acc_bytes = 2 if args.accumulate == 'exact' else 4
     out = dict(label=wl['label'], elapsed=elapsed, gens=gens, denoise_steps=denoise_steps,
                value=world * gens / elapsed, ms_per_step=elapsed / gens * 1e3, keys=sum(h for _, h, _, _ in layers))
@@ -658,7 +673,9 @@ def main():
                                     roofline_finalize=o['roofline_finalize'])
             extra['other_configs'] = others
         if not args.no_integrated and world == 1 and args.workload == 'sdxl1024':
+            note('integrated overhead')
             extra['integrated'] = integrated_overhead(device)
+            note('attend bench')
             # the processor's attention on daam_attend (tools/attend_bench.py): per denoising step of 60 layer calls, next
             # to torch's fused SDPA, and the cost of the in-kernel tap of an immediate (defer_steps=0) trace
             from tools.attend_bench import measure as attend_measure
@@ -666,6 +683,7 @@ def main():
         cpu = None
         if not args.no_baselines and world == 1:
             wl = WORKLOADS[args.workload]
+            note('cpu baseline + eager reference')
             cpu = cpu_baseline(wl['kind'], wl['latent'], denoise, eager_device=device)
             ref_gpu = cpu.pop('eager_mi355x')
             extra['reference_eager_mi355x'] = {k: round(v, 4) for k, v in ref_gpu.items()}
@@ -689,6 +707,7 @@ def main():
     if comm:
         comm.close()
     if rank == 0:
+        note('done')
         print(json.dumps(out), flush=True)
 
 

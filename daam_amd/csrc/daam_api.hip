@@ -33,6 +33,8 @@ hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
 hipError_t launch_upload(void* dst, const void* src_host_mapped, size_t bytes, void* zero, size_t zero_bytes, hipStream_t);
 hipError_t launch_finalize_up32_same(const FinLaunch& up, const FinLaunch& same, hipStream_t, int*);
+hipError_t launch_finalize_up32_pipe(const FinPipeLaunch&, hipStream_t, int*);
+int finalize_pipe_ring();
 hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
 hipError_t launch_finalize_up(const FinLaunch&, int side, int, int mfma_ok, hipStream_t, int*);
 bool finalize_up_supported(int side, int out_side);
@@ -187,12 +189,15 @@ struct DaamCtx {
     void* d_up32_ops = nullptr;        // finalize_up32_mfma_kernel operands of the 32 -> 64 table (see build_up32_ops)
     int up32_tab = -1;
     int no_mfma_finalize = 0;
+    int no_pipe_finalize = 0;         // debugging / A-B: the round-2 x2 MFMA kernel instead of the software-pipelined one
+    void* d_zero_planes = nullptr;    // [tokens][32 x 32] fp16 zeros: padding keys of the pipelined x2 finalize
     int no_paired_finalize = 0;       // debugging / A-B: same-size and x2 class as two launches
     std::vector<Pending> pending;
     std::vector<int> pending_count;   // per layer: recorded steps
     std::vector<int> pending_last;    // per layer: index of its newest entry in `pending`
     void drop_pending() { pending.clear(); pending_count.clear(); pending_last.clear(); }
     int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
+    int last_fin_side = 0;             // finalize class kernels of the last call that ran on auxiliary streams
     int last_flush_kernels = 0, last_flush_side = 0, last_flush_steps = 0;   // daam_last_flush: kernels / of them on side streams / longest step chain
     long long n_flushes = 0;           // tap launches (flushes that launched something) since the context was created
     int profile = 0;
@@ -305,6 +310,18 @@ static void finalize_chunk_ranges(int n_keys, int n_chunks, FinLaunch* L)
     L->chunk_begin[n_chunks] = (int16_t)n_keys;
 }
 
+// auxiliary non-blocking streams + fork / join events of a context (multi-kernel tap flushes, multi-class finalize)
+static hipError_t ensure_aux(DaamCtx* c)
+{
+    if (c->aux_fork) return hipSuccess;
+    hipError_t ae = hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming);
+    for (int i = 0; i < DaamCtx::kAux && ae == hipSuccess; ++i) {
+        ae = hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking);
+        if (ae == hipSuccess) ae = hipEventCreateWithFlags(&c->aux_join[i], hipEventDisableTiming);
+    }
+    return ae;
+}
+
 extern "C" {
 
 int daam_abi_version(void) { return DAAM_ABI_VERSION; }
@@ -339,6 +356,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->force_generic = fg && fg[0] == '1';
     const char* nm = getenv("DAAM_NO_MFMA_FINALIZE");
     c->no_mfma_finalize = nm && nm[0] == '1';
+    const char* npp = getenv("DAAM_NO_PIPE_FINALIZE");
+    c->no_pipe_finalize = npp && npp[0] == '1';
     const char* npf = getenv("DAAM_NO_PAIRED_FINALIZE");
     c->no_paired_finalize = npf && npf[0] == '1';
     const char* n16 = getenv("DAAM_NO_D64");            // debugging: 32x32-tile kernel also for head_dim 64
@@ -375,6 +394,7 @@ int daam_ctx_destroy(DaamCtx* c)
     if (c->clk_stream) (void)hipStreamDestroy(c->clk_stream);
     if (c->clk_host) (void)hipHostFree(c->clk_host);
     if (c->d_up32_ops) (void)hipFree(c->d_up32_ops);
+    if (c->d_zero_planes) (void)hipFree(c->d_zero_planes);
     if (c->d_tab_idx) (void)hipFree(c->d_tab_idx);
     if (c->d_tab_w) (void)hipFree(c->d_tab_w);
     delete c;
@@ -432,6 +452,9 @@ int daam_layer_configure(DaamCtx* c, int layer, int heads, int side, int factor,
                 HIP_TRY(hipMalloc(&c->d_up32_ops, ops.size() * sizeof(_Float16)));
                 HIP_TRY(hipMemcpy(c->d_up32_ops, ops.data(), ops.size() * sizeof(_Float16), hipMemcpyHostToDevice));
                 c->up32_tab = tab;
+                const size_t zb = (size_t)c->tokens * 32 * 32 * sizeof(_Float16);
+                HIP_TRY(hipMalloc(&c->d_zero_planes, zb));
+                HIP_TRY(hipMemset(c->d_zero_planes, 0, zb));
             }
         }
         l.tab = tab;
@@ -814,12 +837,8 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     // non-blocking stream, forked from / joined to the caller's stream by events (all tables are uploaded before
     // the fork) and launched FIRST so that its few workgroups are resident when the large grid fills the rest.
     const bool side = !rc && prepared.size() > 1 && prepared.size() <= (size_t)DaamCtx::kAux + 1 && !c->no_side_stream;
-    if (side && !c->aux_fork) {
-        hipError_t ae = hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming);
-        for (int i = 0; i < DaamCtx::kAux && ae == hipSuccess; ++i) {
-            ae = hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking);
-            if (ae == hipSuccess) ae = hipEventCreateWithFlags(&c->aux_join[i], hipEventDisableTiming);
-        }
+    if (side) {
+        hipError_t ae = ensure_aux(c);
         if (ae != hipSuccess) rc = fail((int)ae, "auxiliary streams: %s", hipGetErrorString(ae));
     }
     size_t main_idx = 0;
@@ -965,24 +984,49 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     hipStream_t s = (hipStream_t)stream;
     const size_t plane = (size_t)c->out_side * c->out_side;
     const size_t out_bytes = sizeof(float) * c->tokens * plane;
+    static const int env_chunks = getenv("DAAM_FIN_CHUNKS") ? atoi(getenv("DAAM_FIN_CHUNKS")) : 0;
+    // x2 class on the matrix cores (fp16 planes, fp16-exact tap matrix)?
+    const bool mfma_up = !keys[1].empty() && c->acc_dtype == DAAM_F16 && keys[1][0].tab == c->up32_tab && c->d_up32_ops &&
+                         c->tab_fp16_exact[keys[1][0].tab] && !c->no_mfma_finalize;
+    // ... on the software-pipelined kernel (daam_finalize_pipe.hip): workgroup = (token, key chunk), every wave walks ALL keys
+    // of its chunk from a pointer table padded with the all-zero plane to one even length >= 4 (+ what the ring prefetches
+    // past the end).  ~1000 workgroups of 2 waves = one resident round at 2 waves per SIMD.
+    const bool pipe_up = mfma_up && !c->no_pipe_finalize && c->d_zero_planes;
+    int pipe_chunks = 0, pipe_nk = 0, pipe_stride = 0;
+    if (pipe_up) {
+        const int n = (int)keys[1].size();
+        const int want = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
+        pipe_chunks = std::max(1, std::min(want, (n + 7) / 8));
+        const int per = (n + pipe_chunks - 1) / pipe_chunks;
+        pipe_nk = std::max(4, (per + 1) & ~1);
+        pipe_stride = (pipe_nk + finalize_pipe_ring() + 2) & ~1;
+    }
     size_t off = 0;
-    const size_t bytes = (size_t)total * sizeof(FinKey);
+    const size_t key_bytes = ((size_t)total * sizeof(FinKey) + 63) & ~size_t(63);
+    const size_t bytes = key_bytes + (size_t)pipe_chunks * pipe_stride * sizeof(unsigned long long);
     HIP_TRY(c->ring.alloc(bytes, &off));
     {
         FinKey* dst = reinterpret_cast<FinKey*>(c->ring.host + off);
         for (auto& v : keys) { memcpy(dst, v.data(), v.size() * sizeof(FinKey)); dst += v.size(); }
+        if (pipe_up) {
+            unsigned long long* pt = reinterpret_cast<unsigned long long*>(c->ring.host + off + key_bytes);
+            const unsigned long long zero = reinterpret_cast<unsigned long long>(c->d_zero_planes);
+            const int n = (int)keys[1].size(), per = (n + pipe_chunks - 1) / pipe_chunks;
+            for (int ch = 0; ch < pipe_chunks; ++ch)
+                for (int j = 0; j < pipe_stride; ++j) {
+                    const int k = ch * per + j;
+                    pt[(size_t)ch * pipe_stride + j] = (j < per && k < n) ? reinterpret_cast<unsigned long long>(keys[1][k].base) : zero;
+                }
+        }
     }
     const FinKey* dev = reinterpret_cast<const FinKey*>(c->ring.dev + off);
     c->last_block[1] = 256;
     c->last_grid[1] = 0;
     c->last_lds[1] = 0;
-    static const int env_chunks = getenv("DAAM_FIN_CHUNKS") ? atoi(getenv("DAAM_FIN_CHUNKS")) : 0;
-    // x2 class on the matrix cores (fp16 planes, fp16-exact tap matrix)?  Decided BEFORE the chunking: that kernel walks a
-    // host-built chunk table of at most kFinMaxChunks chunks x 2 key lanes x 64 keys, so a larger class goes out as several
-    // launches over key sub-ranges (kFinMfmaKeysPerLaunch each) -- the LDS kernel and the other classes take any key count.
+    // The round-2 MFMA kernel (DAAM_NO_PIPE_FINALIZE=1) walks a host-built chunk table of at most kFinMaxChunks chunks x 2 key
+    // lanes x 64 keys, so a larger class goes out as several launches over key sub-ranges (kFinMfmaKeysPerLaunch each) -- the
+    // pipelined kernel, the LDS kernel and the other classes take any key count.
     constexpr int kFinMfmaKeysPerLaunch = kFinMaxChunks * 128;
-    const bool mfma_up = !keys[1].empty() && c->acc_dtype == DAAM_F16 && keys[1][0].tab == c->up32_tab && c->d_up32_ops &&
-                         c->tab_fp16_exact[keys[1][0].tab] && !c->no_mfma_finalize;
     // x2 class chunking: ~1000 workgroups (one full round at 4 workgroups per CU) measured best -- fewer leaves a ragged
     // tail, more pays the per-workgroup reduction + atomics too often; every key lane of a chunk takes at most 64 keys
     const int want_up = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
@@ -1021,7 +1065,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     }
     // the MFMA kernel's launches: key sub-ranges of at most kFinMfmaKeysPerLaunch keys, each with its own chunk table
     std::vector<FinLaunch> up_parts;
-    if (mfma_up) {
+    if (mfma_up && !pipe_up) {
         const FinLaunch& U = launches[1];
         for (int begin = 0; begin < U.n_keys; begin += kFinMfmaKeysPerLaunch) {
             FinLaunch P = U;
@@ -1034,7 +1078,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         launches[1] = up_parts[0];                             // what the paired launch takes (single part)
     }
     // SDXL-1024 in fp16: the same-size and the x2 class side by side in ONE launch
-    const bool paired = mfma_up && up_parts.size() == 1 && have[0] && !c->no_paired_finalize;
+    const bool paired = mfma_up && !pipe_up && up_parts.size() == 1 && have[0] && !c->no_paired_finalize;
     // the output is accumulated with atomics: zero it in the table-upload launch
     const bool zero_in_upload = out_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
     if (!zero_in_upload) {
@@ -1049,31 +1093,74 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             return fail((int)ce, "table upload: %s", hipGetErrorString(ce));
         }
     }
-    for (int cls = 0; cls < kClasses; ++cls) {
-        if (!have[cls] || (paired && cls == 0)) continue;
+    // Several classes: the issue-bound x2 kernel keeps the caller's stream; every other class (HBM streams with few
+    // registers: their waves fit beside the two heavy waves of a SIMD) goes to an auxiliary stream forked from / joined to the
+    // caller's by events, launched FIRST -- SDXL-1024: 63 MB of same-size planes stream under 158 MB of x2 planes; SD-v1.5:
+    // three classes side by side instead of three serial launches.
+    int n_classes = 0;
+    for (int cls = 0; cls < kClasses; ++cls) n_classes += have[cls] ? 1 : 0;
+    bool fork = pipe_up && n_classes > 1 && n_classes <= DaamCtx::kAux + 1 && !c->no_side_stream;
+    if (fork) {
+        hipError_t ae = ensure_aux(c);
+        if (ae != hipSuccess || hipEventRecord(c->aux_fork, s) != hipSuccess) fork = false;    // serial launches still correct
+    }
+    int n_side = 0;
+    auto launch_class = [&](int cls, hipStream_t ks, int* grid, int* lds) -> hipError_t {
         const FinLaunch& L = launches[cls];
-        int grid = 0, lds = 0;
-        hipError_t e;
-        if (cls == 1 && paired) e = launch_finalize_up32_same(L, launches[0], s, &grid);
-        else if (cls == 1 && mfma_up) {
-            e = hipSuccess;
+        if (cls == 1 && pipe_up) {
+            FinPipeLaunch P;
+            P.key_ptrs = reinterpret_cast<const unsigned long long*>(c->ring.dev + off + key_bytes);
+            P.mfma_ops = c->d_up32_ops;
+            P.out = out;
+            P.n_chunks = pipe_chunks;
+            P.nk_pad = pipe_nk;
+            P.ptr_stride = pipe_stride;
+            P.tokens = c->tokens;
+            P.inv_n = L.inv_n;
+            return launch_finalize_up32_pipe(P, ks, grid);
+        }
+        if (cls == 1 && paired) return launch_finalize_up32_same(L, launches[0], ks, grid);
+        if (cls == 1 && mfma_up) {
+            hipError_t e = hipSuccess;
             for (size_t part = 0; part < up_parts.size() && e == hipSuccess; ++part) {
                 int g = 0;
-                e = launch_finalize_up(up_parts[part], 32, c->acc_dtype, 1, s, &g);
-                grid += g;
+                e = launch_finalize_up(up_parts[part], 32, c->acc_dtype, 1, ks, &g);
+                *grid += g;
             }
+            return e;
         }
-        else if (cls == 0) e = launch_finalize_same(L, c->acc_dtype, s, &grid);
-        else if (cls == 3) e = launch_finalize(L, c->acc_dtype, s, &grid, &lds);
-        else if (cls == 4) e = launch_finalize_down2(L, c->acc_dtype, s, &grid);
-        else e = launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, 0, s, &grid);
+        if (cls == 0) return launch_finalize_same(L, c->acc_dtype, ks, grid);
+        if (cls == 3) return launch_finalize(L, c->acc_dtype, ks, grid, lds);
+        if (cls == 4) return launch_finalize_down2(L, c->acc_dtype, ks, grid);
+        return launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, 0, ks, grid);
+    };
+    const int order[kClasses] = {0, 2, 3, 4, 1};                       // the x2 class last: side kernels are resident when it fills the chip
+    for (int oi = 0; oi < kClasses; ++oi) {
+        const int cls = order[oi];
+        if (!have[cls] || (paired && cls == 0)) continue;
+        hipStream_t ks = s;
+        const bool on_side = fork && cls != 1;
+        if (on_side) {
+            ks = c->aux_stream[n_side];
+            if (hipStreamWaitEvent(ks, c->aux_fork, 0) != hipSuccess) ks = s;
+        }
+        int grid = 0, lds = 0;
+        hipError_t e = launch_class(cls, ks, &grid, &lds);
+        if (e == hipSuccess && ks != s) {
+            e = hipEventRecord(c->aux_join[n_side], ks);
+            ++n_side;
+        }
         if (e != hipSuccess) {
+            for (int i = 0; i < n_side; ++i) (void)hipStreamWaitEvent(s, c->aux_join[i], 0);
             (void)c->ring.release(s);                      // the table region is reusable once whatever did launch has run
             return fail((int)e, "finalize launch (class %d): %s", cls, hipGetErrorString(e));
         }
         c->last_grid[1] += grid;
         c->last_lds[1] = std::max(c->last_lds[1], lds);
     }
+    for (int i = 0; i < n_side; ++i)
+        if (hipStreamWaitEvent(s, c->aux_join[i], 0) != hipSuccess) { (void)c->ring.release(s); return fail(DAAM_E_STATE, "stream join failed"); }
+    c->last_fin_side = n_side;
     if (c->profile) (void)hipEventRecord(c->prof_ev[1][1], s);
     HIP_TRY(c->ring.release(s));
     return 0;

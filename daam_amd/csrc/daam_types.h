@@ -110,6 +110,20 @@ struct FinLaunch {
     int16_t chunk_begin[kFinMaxChunks + 1];
 };
 
+// x2 finalize, software-pipelined kernel (daam_finalize_pipe.hip): workgroup (token, chunk) walks the plane pointers
+// key_ptrs[chunk * ptr_stride + 0 .. nk_pad) (token 0's plane of each key, or the all-zero plane as padding; nk_pad even, >= 4,
+// the same for every chunk; the ring prefetches kPipeRing + 1 entries past nk_pad, which must be valid pointers too).
+struct FinPipeLaunch {
+    const unsigned long long* key_ptrs;
+    const void* mfma_ops;   // as FinLaunch::mfma_ops
+    float* out;             // [tokens, 64, 64]
+    int32_t n_chunks;
+    int32_t nk_pad;
+    int32_t ptr_stride;     // entries per chunk in key_ptrs
+    int32_t tokens;
+    float inv_n;
+};
+
 // bfloat16 storage type (no arithmetic): values cross to f32 by a shift, back by round-to-nearest-even
 struct bf16_t { uint16_t bits; };
 __host__ __device__ inline float bf16_to_f32(bf16_t v) {

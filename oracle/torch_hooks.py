@@ -21,15 +21,28 @@ import torch
 import torch.nn.functional as F
 
 
+def _auto_autocast(*args, **kwargs):
+    """The reference's ``auto_autocast`` (daam/utils.py:32-36), which wraps the unravel loop (trace.py:237), every
+    ``update`` (heatmap.py:154) and ``compute_global_heat_map`` (trace.py:111): entering it 1100+ times per SDXL denoising
+    step is part of the host cost being timed (tools/port_vs_reference_cpu.py: without it the port ran 24 % faster than the
+    reference).  It changes no value here: none of the wrapped ops of the per-step path is an autocast op, and the bicubic
+    input is up-cast explicitly below."""
+    if not torch.cuda.is_available():
+        kwargs['enabled'] = False
+    return torch.cuda.amp.autocast(*args, **kwargs)
+
+
 @torch.no_grad()
 def unravel(x: torch.Tensor) -> torch.Tensor:
     """``[BH, hw, tokens] -> [kept, tokens, h, w]`` by the reference's op sequence: permute,
     one view + slice per token (77 Python iterations), stack, permute, contiguous."""
     side = int(math.sqrt(x.size(1)))
     planes = []
-    for per_token in x.permute(2, 0, 1):                       # trace.py:235,238
-        per_token = per_token.view(per_token.size(0), side, side)
-        planes.append(per_token[per_token.size(0) // 2:])      # conditional half, trace.py:240
+    x = x.permute(2, 0, 1)                                      # trace.py:235
+    with _auto_autocast(dtype=torch.float32):                   # trace.py:237
+        for per_token in x:                                     # trace.py:238
+            per_token = per_token.view(per_token.size(0), side, side)
+            planes.append(per_token[per_token.size(0) // 2:])  # conditional half, trace.py:240
     return torch.stack(planes, 0).permute(1, 0, 2, 3).contiguous()
 
 
@@ -38,9 +51,10 @@ class RawMaps:
         self.maps = OrderedDict()
 
     def update(self, factor: int, layer: int, head: int, heat_map: torch.Tensor):
-        key = (factor, layer, head)
-        prev = self.maps.get(key)
-        self.maps[key] = heat_map + 0.0 if prev is None else prev + heat_map   # out-of-place add, heatmap.py:156
+        with _auto_autocast(dtype=torch.float32):                           # heatmap.py:154
+            key = (factor, layer, head)
+            prev = self.maps.get(key)
+            self.maps[key] = heat_map + 0.0 if prev is None else prev + heat_map   # out-of-place add, heatmap.py:156
 
     def clear(self):
         self.maps.clear()

@@ -201,12 +201,14 @@ def test_tap_probs_bit_exact(dt):
 
 @pytest.mark.parametrize('sides', [(64,), (32,), (16, 32, 64), (128, 64), (8,), (24, 48)])
 @pytest.mark.parametrize('acc', ['float16', 'float32', 'bfloat16'])
-@pytest.mark.parametrize('path', ['default', 'no_mfma', 'general'])
+@pytest.mark.parametrize('path', ['default', 'no_pipe', 'no_mfma', 'general'])
 def test_finalize_vs_oracle(sides, acc, path, monkeypatch):
     """bicubic (A=-0.75, border-clamped taps) -> clamp -> mean over keys, incl. the x0.5
     down-sample of SDXL-2048 (128 -> 64) and the 96x96 output of 768-px models."""
-    # default: MFMA x-pass for fp16 32 -> 64; no_mfma: the LDS / packed-f32 kernel; general: the any-size kernel
+    # default: the software-pipelined MFMA kernel for fp16 32 -> 64 (other classes beside it on auxiliary streams); no_pipe: round 2's
+    # MFMA kernel; no_mfma: the LDS / packed-f32 kernel; general: the any-size kernel
     monkeypatch.setenv('DAAM_NO_MFMA_FINALIZE', '1' if path == 'no_mfma' else '0')
+    monkeypatch.setenv('DAAM_NO_PIPE_FINALIZE', '1' if path == 'no_pipe' else '0')
     monkeypatch.setenv('DAAM_FORCE_GENERIC', '1' if path == 'general' else '0')
     rng = np.random.default_rng(len(sides) * 31 + sides[0])
     out_side = 96 if 24 in sides else 64
@@ -233,13 +235,14 @@ def test_finalize_vs_oracle(sides, acc, path, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize('n_keys,path', [(4800, 'default'), (8100, 'default'), (8100, 'no_mfma')])
+@pytest.mark.parametrize('n_keys,path', [(4800, 'default'), (8100, 'default'), (8100, 'no_mfma'), (4800, 'no_pipe'), (8100, 'no_pipe')])
 def test_finalize_many_x2_keys(n_keys, path, monkeypatch):
     """More 32 x 32 keys than ONE launch of a x2 kernel covers (the MFMA kernel: 31 chunks x 2 key lanes x 64 = 3968; SDXL-1024
     with num_images_per_prompt = 4 has 60 layers x 80 kept heads = 4800): the class is split over several launches, no key
     is dropped.  Key i holds plane set (i mod 81) scaled by 2^-(i div 81 mod 4): bicubic and clamp are positively
     homogeneous, so the expected mean follows from 81 oracle maps -- and dropping ANY subset of keys changes it."""
     monkeypatch.setenv('DAAM_NO_MFMA_FINALIZE', '1' if path == 'no_mfma' else '0')
+    monkeypatch.setenv('DAAM_NO_PIPE_FINALIZE', '1' if path == 'no_pipe' else '0')
     rng = np.random.default_rng(n_keys)
     base_n, side = 81, 32
     base = (rng.standard_normal((base_n, side * side, 77)) * 3).astype(np.float16)         # signed: the clamp matters
@@ -262,6 +265,40 @@ def test_finalize_many_x2_keys(n_keys, path, monkeypatch):
     assert np.abs(got - want).max() <= 3e-6 * max(1.0, np.abs(want).max())
     sel = eng.global_heat_map(head_idx=n_keys - 1).cpu().numpy()                           # the last key alone
     np.testing.assert_allclose(sel, scales[-1] * per_key[(n_keys - 1) % base_n], rtol=0, atol=3e-6 * np.abs(per_key).max())
+    eng.close()
+
+
+@pytest.mark.parametrize('n_keys', [1, 2, 3, 5, 8, 13, 27, 104, 105, 1000, 1001])
+def test_finalize_pipe_key_counts(n_keys, monkeypatch):
+    """The software-pipelined x2 kernel walks a pointer table padded with all-zero planes to an even length >= 4 per chunk:
+    key counts around every padding / chunking boundary (1 key = 3 padding planes; 13 chunks from 104 keys on; odd shares),
+    with a same-size layer beside it (second stream).  Key i = plane set (i mod 27) scaled by 2^-(i mod 3)."""
+    monkeypatch.setenv('DAAM_NO_MFMA_FINALIZE', '0')
+    monkeypatch.setenv('DAAM_NO_PIPE_FINALIZE', '0')
+    rng = np.random.default_rng(1000 + n_keys)
+    base_n, side = 27, 32
+    base = (rng.standard_normal((base_n, side * side, 77)) * 3).astype(np.float16)
+    per_key = np.stack([ho.global_heat_map([((2, 0, 0), ho.unravel(np.concatenate([base[i:i + 1]] * 2))[0])], 4096)
+                        for i in range(base_n)]).astype(np.float64)
+    scales = 2.0 ** -(np.arange(n_keys) % 3)
+    same = (rng.standard_normal((2 * 2, 64 * 64, 77)) * 3).astype(np.float16)             # layer 1: two 64 x 64 keys
+    same_maps = [ho.global_heat_map([((1, 1, h), ho.unravel(same)[h])], 4096).astype(np.float64) for h in range(2)]
+    want = sum(same_maps)
+    for i in range(n_keys):
+        want = want + scales[i] * per_key[i % base_n]
+    want /= n_keys + 2
+    eng = _engine(n_layers=2, accumulate='exact')
+    bd = torch.from_numpy(base).to(DEV)
+    idx = torch.arange(n_keys, device=DEV)
+    planes = bd[idx % base_n] * torch.from_numpy(scales.astype(np.float16)).to(DEV)[:, None, None]
+    eng.tap_probs(0, torch.cat([torch.zeros_like(planes), planes]), factor=2)
+    eng.tap_probs(1, torch.from_numpy(same).to(DEV), factor=1)
+    for _ in range(2):                                                                     # twice: the table ring advances
+        got = eng.global_heat_map().cpu().numpy()
+        assert np.abs(got - want).max() <= 3e-6 * max(1.0, np.abs(want).max()), n_keys
+    only = eng.global_heat_map(factors=[2]).cpu().numpy()                                  # the x2 class alone (no second stream)
+    want2 = sum(scales[i] * per_key[i % base_n] for i in range(n_keys)) / n_keys
+    assert np.abs(only - want2).max() <= 3e-6 * max(1.0, np.abs(want2).max())
     eng.close()
 
 
@@ -426,11 +463,14 @@ def test_trace_api_matches_reference_golden(golden_case, tap, defer, tmp_path):
 
 
 @pytest.mark.parametrize('env', [dict(DAAM_STRICT_EXP='1'), dict(DAAM_NO_D64='1'), dict(DAAM_NO_D64='1', DAAM_STRICT_EXP='1'),
-                                 dict(DAAM_FORCE_GENERIC='1')])
+                                 dict(DAAM_FORCE_GENERIC='1'), dict(DAAM_NO_PIPE_FINALIZE='1'),
+                                 dict(DAAM_NO_PIPE_FINALIZE='1', DAAM_NO_PAIRED_FINALIZE='1'), dict(DAAM_NO_SIDE_STREAM='1')])
 def test_optional_kernel_paths_keep_parity(env, monkeypatch):
     """The opt-in / fallback kernel variants (compensated-exp softmax, the 32x32-tile MFMA kernel instead of the
     head_dim-64 one, the any-shape kernels) stay within the same tolerances on an SDXL-shaped fp16 case (head_dim 64)."""
     import daam_amd
+    from daam_amd import engine as E
+    E.release_parked_contexts()                                  # the switches are read when a context is created
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     from oracle import fake_diffusers as fd

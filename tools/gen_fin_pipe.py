@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""Generates daam_amd/csrc/daam_finalize_pipe_asm.inc: the software-pipelined main loop of the x2 (32 -> 64) finalize on the
+matrix cores as ONE hand-scheduled inline-asm statement (fixed physical registers, counted waits, LDS-DMA plane ring).
+
+    python tools/gen_fin_pipe.py            # rewrites the .inc (committed next to this script's output)
+
+Why a generator: the loop is a two-deep software pipeline over planes with double-buffered registers -- per iteration i
+    C(i)    pass 2 of plane i:   8 MFMA 32x32x16  (o[pi] = Wy x (hi + lo of T(i)) + acc[pi]),  pi = i & 1
+    D(i-1)  clamp + accumulate of plane i-1: 32 v_max_i32  (acc[1-pi] = max(o[1-pi], acc[1-pi]))
+    B(i+1)  hi / lo split of T(i+1): 8 v_cvt_pk + 16 v_fma_mix + 8 v_cvt_pk -> B[1-pi]
+    A(i+2)  pass 1 of plane i+2: 2 MFMA (T = P x Wx^T), plane from the LDS ring
+    + DMA of plane i+1+R into the ring slot plane i+1 left, the next key pointer by s_load
+-- and every VALU instruction sits in a fixed gap behind an MFMA that does not depend on it (6-7 per gap: the measured issue
+budget of a gfx950 SIMD).  hipcc cannot be talked into this schedule (it re-serialises the stages and
+ties vdst = srcC), and an asm statement gets no hazard padding from it: the distances below ARE the hazard handling
+(cdna_hip_programming.md section 5.7):
+  * MFMA result -> VALU read: >= 2 later MFMAs of the in-order matrix pipe issued in between (>= 64 cycles; 12 states needed);
+  * VALU write -> MFMA operand: >= 2 instructions in between;  T is rewritten by A(i+2) only after every B(i+1) instruction;
+  * LDS-DMA -> ds_read: the issuing wave's counted vmcnt (the ring is wave-private: no barrier);  ds_read -> MFMA: lgkmcnt(0);
+  * ring slot reuse: the DMA into slot (i+1) % R is issued after the lgkmcnt(0) that retired plane i+1's reads.
+"""
+import os
+
+R = 8                     # ring slots (planes) per wave, 2 KiB each
+SLOT = 2048
+# ---- register map --------------------------------------------------------------------------------------------------
+WX = (0, 4)               # B operands of pass 1 (4 VGPRs each)
+WY = {(0, 0): 8, (0, 1): 12, (1, 0): 16, (1, 1): 20}    # wy[t][ks]: A operands of pass 2
+P = (24, 28)              # plane pieces (A operands of pass 1)
+T = 32                    # 16
+def BSET(s): return 48 + 16 * s          # bhi0 +0, bhi1 +4, blo0 +8, blo1 +12
+def OSET(s): return 80 + 32 * s          # o0 +0, o1 +16
+def ASET(s): return 144 + 32 * s         # acc0 +0, acc1 +16
+GOFF_LO, GOFF_HI, LDS_RD, LDS_TMP = 208, 209, 210, 211
+S_KEYS = '36:37'
+S_KOFF, S_TRIPS, S_RING, S_RDSLOT, S_DMASLOT, S_M0SAVE = 38, 39, 42, 43, 44, 47
+S_BASE = '40:41'
+S_PRE = 48                # s[48:63]: the first 8 plane pointers
+
+def vr(b, n): return f'v[{b}:{b + n - 1}]'
+def mfma(d, a, b, c): return f'v_mfma_f32_32x32x16_f16 {vr(d, 16)}, {vr(a, 4)}, {vr(b, 4)}, ' + ('0' if c is None else vr(c, 16))
+
+def stage_C(pi):
+    o, a, b = OSET(pi), ASET(pi), BSET(pi)
+    return [mfma(o, WY[0, 0], b + 0, a), mfma(o + 16, WY[1, 0], b + 0, a + 16),
+            mfma(o, WY[0, 1], b + 4, o), mfma(o + 16, WY[1, 1], b + 4, o + 16),
+            mfma(o, WY[0, 0], b + 8, o), mfma(o + 16, WY[1, 0], b + 8, o + 16),
+            mfma(o, WY[0, 1], b + 12, o), mfma(o + 16, WY[1, 1], b + 12, o + 16)]
+
+def stage_A():
+    return [mfma(T, P[0], WX[0], None), mfma(T, P[1], WX[1], T)]
+
+def stage_D(s):
+    o, a = OSET(s), ASET(s)
+    return [f'v_max_i32 v{a + r}, v{o + r}, v{a + r}' for r in range(32)]
+
+def stage_B(s):
+    b = BSET(s)
+    L = [f'v_cvt_pk_f16_f32 v{b + w}, v{T + 2 * w}, v{T + 2 * w + 1}' for w in range(8)]            # hi (bhi0 = +0..3, bhi1 = +4..7)
+    for j in range(16):                                                                              # lo = T - hi, in place
+        sel = ' op_sel:[1,0,0]' if j & 1 else ''
+        L.append(f'v_fma_mix_f32 v{T + j}, v{b + j // 2}, -1.0, v{T + j}{sel} op_sel_hi:[1,0,0]')
+    L += [f'v_cvt_pk_f16_f32 v{b + 8 + w}, v{T + 2 * w}, v{T + 2 * w + 1}' for w in range(8)]        # lo
+    return L
+
+def dma(base):
+    """plane -> ring slot S_DMASLOT (two 1 KiB pieces), then advance the slot"""
+    return [f's_add_u32 m0, s{S_RING}, s{S_DMASLOT}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF_LO}, s[{base}]',
+            's_add_u32 m0, m0, 0x400', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF_HI}, s[{base}]',
+            f's_add_u32 s{S_DMASLOT}, s{S_DMASLOT}, {SLOT}', f's_and_b32 s{S_DMASLOT}, s{S_DMASLOT}, {R * SLOT - 1}']
+
+def next_key():
+    return [f's_load_dwordx2 s[{S_BASE}], s[{S_KEYS}], s{S_KOFF}', f's_add_u32 s{S_KOFF}, s{S_KOFF}, 8']
+
+def read_plane():
+    return [f'v_add_u32 v{LDS_TMP}, s{S_RDSLOT}, v{LDS_RD}', f'ds_read_b128 {vr(P[0], 4)}, v{LDS_TMP}',
+            f'ds_read_b128 {vr(P[1], 4)}, v{LDS_TMP} offset:32',
+            f's_add_u32 s{S_RDSLOT}, s{S_RDSLOT}, {SLOT}', f's_and_b32 s{S_RDSLOT}, s{S_RDSLOT}, {R * SLOT - 1}']
+
+GAPS = [6, 6, 6, 7, 6, 7, 6, 7, 6, 7]       # VALU per MFMA gap (64 per iteration)
+
+def iteration(pi, do_c=True, do_d=True, do_b=True, do_a=True, do_dma=True):
+    """one pipeline step for parity pi: C(i) | D(i-1) on set 1-pi | B(i+1) -> set 1-pi | A(i+2)"""
+    L = []
+    if do_a:
+        L += [f's_waitcnt vmcnt({2 * (R - 2)})'] + read_plane()
+    m = (stage_C(pi) if do_c else []) + (stage_A() if do_a else [])
+    d = stage_D(1 - pi) if do_d else []
+    b = stage_B(1 - pi) if do_b else []
+    # VALU order: the first 12 clamps (gaps 0-1: T of the previous A is not readable yet), the split (gaps 2-6, complete
+    # before A rewrites T), the remaining clamps
+    valu = d[:12] + b + d[12:]
+    k = 0
+    for gi, ins in enumerate(m):
+        is_a0 = do_a and ins is m[-2]
+        if is_a0:
+            pass                                    # lgkmcnt(0) was waited in gap 5
+        L.append(ins)
+        n = GAPS[gi] if (do_c and do_a) else (len(valu) + len(m) - 1) // len(m)
+        L += valu[k:k + n]
+        k += n
+        if do_dma and do_c and gi == 5:
+            L += ['s_waitcnt lgkmcnt(0)'] + dma(S_BASE)[:3]
+        if do_dma and do_c and gi == 6:
+            L += dma(S_BASE)[3:] + next_key()
+    L += valu[k:]
+    return L
+
+def build():
+    L = [f's_mov_b32 s{S_M0SAVE}, m0']
+    # running sums and the o set the first D reads: zero
+    L += [f'v_mov_b32 v{r}, 0' for r in list(range(ASET(0), ASET(0) + 64)) + list(range(OSET(1), OSET(1) + 32))]
+    L += [f's_load_dwordx16 s[{S_PRE}:{S_PRE + 15}], s[{S_KEYS}], 0x0', f's_load_dwordx2 s[{S_BASE}], s[{S_KEYS}], 0x{8 * R:x}',
+          f's_mov_b32 s{S_KOFF}, 0x{8 * (R + 1):x}', f's_mov_b32 s{S_RDSLOT}, 0', f's_mov_b32 s{S_DMASLOT}, 0', 's_waitcnt lgkmcnt(0)']
+    for q in range(R):                                                        # prefill the ring: planes 0 .. R-1
+        L += [f's_add_u32 m0, s{S_RING}, 0x{q * SLOT:x}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF_LO}, s[{S_PRE + 2 * q}:{S_PRE + 2 * q + 1}]',
+              f's_add_u32 m0, s{S_RING}, 0x{q * SLOT + 1024:x}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF_HI}, s[{S_PRE + 2 * q}:{S_PRE + 2 * q + 1}]']
+    # i = -2: A(0)
+    L += [f's_waitcnt vmcnt({2 * (R - 1)})'] + read_plane() + ['s_waitcnt lgkmcnt(0)'] + stage_A()
+    # i = -1: B(0) -> set 0, A(1); DMA of plane R into slot 0
+    L += [f's_waitcnt vmcnt({2 * (R - 2)})'] + read_plane()
+    L += ['s_nop 15', 's_nop 15']                                             # T(0): the 2 MFMAs above -> first VALU read
+    L += stage_B(0)
+    L += ['s_waitcnt lgkmcnt(0)'] + stage_A() + dma(S_BASE) + next_key()
+    # steady state: i = 0 .. NK-3, two iterations per trip
+    L += ['L_fin_top%=:'] + iteration(0) + iteration(1)
+    L += [f's_sub_u32 s{S_TRIPS}, s{S_TRIPS}, 1', f's_cmp_lg_u32 s{S_TRIPS}, 0', 's_cbranch_scc1 L_fin_top%=']
+    # i = NK-2 (parity 0): C, D(NK-3), B(NK-1); i = NK-1 (parity 1): C, D(NK-2); then D(NK-1)
+    L += iteration(0, do_a=False, do_dma=False)
+    L += iteration(1, do_a=False, do_b=False, do_dma=False)
+    L += ['s_nop 15', 's_nop 15'] + stage_D(1)
+    L += ['s_waitcnt vmcnt(0)', f's_mov_b32 m0, s{S_M0SAVE}']
+    return L
+
+def main():
+    lines = build()
+    used_v = sorted(set(range(P[0], GOFF_LO)) - set(range(ASET(0), ASET(0) + 64))) + [LDS_TMP]
+    clob = [f'"v{r}"' for r in used_v] + [f'"s{r}"' for r in [S_KOFF, 40, 41, S_RDSLOT, S_DMASLOT, 45, S_M0SAVE] + list(range(S_PRE, S_PRE + 16))]
+    clob += ['"memory"', '"scc"', '"vcc"']
+    out = ['// GENERATED by tools/gen_fin_pipe.py -- do not edit; the schedule and its hazard distances are documented there.',
+           '// One asm statement: prologue, software-pipelined loop over the planes of this wave, drain.',
+           f'// {sum(1 for l in lines if l.startswith("v_mfma"))} MFMA + {sum(1 for l in lines if l.startswith("v_") and not l.startswith("v_mfma"))} VALU statements in the text; ring of {R} planes.',
+           'asm volatile(']
+    for l in lines:
+        out.append(f'    "{l}\\n\\t"')
+    out.append('    : "={v[144:159]}"(accA0), "={v[160:175]}"(accA1), "={v[176:191]}"(accB0), "={v[192:207]}"(accB1), "+{s39}"(trips)')
+    out.append('    : "{v[0:3]}"(wx0), "{v[4:7]}"(wx1), "{v[8:11]}"(wy00), "{v[12:15]}"(wy01), "{v[16:19]}"(wy10), "{v[20:23]}"(wy11),')
+    out.append('      "{v208}"(goff_lo), "{v209}"(goff_hi), "{v210}"(lds_rd), "{s[36:37]}"(key_ptrs), "{s42}"(ring_base)')
+    out.append('    : ' + ', '.join(clob) + ');')
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'daam_amd', 'csrc', 'daam_finalize_pipe_asm.inc')
+    open(path, 'w').write('\n'.join(out) + '\n')
+    per_iter = iteration(0)
+    print('wrote', path, len(lines), 'instructions;', 'steady iteration:', len(per_iter), 'instructions,',
+          sum(1 for l in per_iter if l.startswith('v_mfma')), 'MFMA')
+
+if __name__ == '__main__':
+    main()
