@@ -43,7 +43,7 @@ hipError_t launch_finalize_down2(const FinLaunch&, int, hipStream_t, int*);
 hipError_t launch_normalize(float*, int, int, hipStream_t);
 hipError_t launch_mask_overlap(const float*, int, int, const float*, int, int, int, float*, hipStream_t);
 bool attend_d64_supported(int in_dtype, int head_dim, int tokens, const int64_t* strides, int n_strides, const void* const* ptrs, int n_ptrs);
-hipError_t launch_attend_d64(const AttendLaunch&, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
+hipError_t launch_attend_d64(const AttendLaunch&, int in_dtype, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
 hipError_t launch_clock_monitor(unsigned long long* samples, int n_samples, int period_us, hipStream_t);
 constexpr int kClockMaxSamples = 4096;
 hipError_t launch_word(const float*, int, const int32_t*, int, float*, float*, int, int, int, float, float*,
@@ -647,7 +647,11 @@ int daam_attend(DaamCtx* c, int layer, const void* q, const void* k, const void*
 {
     if (!c || !d || !q || !k || !v || !out) return fail(DAAM_E_INVALID, "NULL argument");
     if (!daam_attend_supported(d, q, k, v, out))
-        return fail(DAAM_E_UNSUPPORTED, "daam_attend: fp16, head_dim %% 8 == 0 up to 160, 77 tokens, hw %% 8 == 0, strides %% 8 == 0, 16-byte aligned pointers only");
+        return fail(DAAM_E_UNSUPPORTED, "daam_attend: fp16 / bf16, head_dim %% 8 == 0 up to 160, 77 tokens, hw %% 8 == 0, strides %% 8 == 0, 16-byte aligned pointers only");
+    if (d->qk.in_dtype == DAAM_BF16 && !d->qk.round_logits)
+        return fail(DAAM_E_UNSUPPORTED, "daam_attend: bf16 pipelines with upcast_attention (f32 logits) take the framework's attention");
+    if (!dtypes_compatible(d->qk.in_dtype, c->acc_dtype))
+        return fail(DAAM_E_UNSUPPORTED, "daam_attend: activations of dtype %d on a context whose sums are dtype %d", d->qk.in_dtype, c->acc_dtype);
     if (d->qk.tokens != c->tokens) return fail(DAAM_E_INVALID, "tokens %d != context size %d", d->qk.tokens, c->tokens);
     if (tap) {
         int rc = check_qk(c, layer, q, k, &d->qk);
@@ -674,7 +678,7 @@ int daam_attend(DaamCtx* c, int layer, const void* q, const void* k, const void*
         L.fresh = c->layers[layer].dirty ? 0 : 1;
     }
     int grid = 0, lds = 0;
-    hipError_t e = launch_attend_d64(L, c->acc_dtype, c->fast_exp && d->qk.round_logits, (hipStream_t)stream, &grid, &lds);
+    hipError_t e = launch_attend_d64(L, d->qk.in_dtype, c->acc_dtype, c->fast_exp && d->qk.round_logits, (hipStream_t)stream, &grid, &lds);
     if (e != hipSuccess) return fail((int)e, "attend launch: %s", hipGetErrorString(e));
     if (tap) {
         c->last_grid[0] = grid;

@@ -17,7 +17,7 @@
 // [batch, hw, heads*64] layout the output projection consumes (no transpose / reshape copy afterwards).
 // LDS (head_dim 64): K [80 rows][160 B] (A operand of S^T), V^T [64 rows][96 key slots, 208 B] (A operand of O^T), and for the
 // tap a [77][128] fp16 tile of probabilities that turns the lanes' scattered 2-byte values into 16-byte row pieces of the sums.
-#include "daam_tap16.h"
+#include "daam_tap16_softmax.h"
 
 namespace daam {
 
@@ -130,7 +130,9 @@ template <int KS, int DT> struct AttendShape {
     static constexpr int kKCh = (kTok * kPieces + 255) / 256;  // pieces per thread
 };
 
-template <typename ACC_T, bool FAST_EXP, int KS, int DT>
+// IN = InF16 / InBF16 (daam_tap16_softmax.h): the pipeline dtype selects the MFMA, the rounding points of logits, probabilities
+// and output, and how the tap adds (bf16 pipelines: one softmax flavour, logits always rounded -- the host declines the rest)
+template <typename IN, typename ACC_T, bool FAST_EXP, int KS, int DT>
 __global__ __launch_bounds__(256, 2) void attend_kernel(const AttendLaunch L)
 {
     using S = AttendShape<KS, DT>;
@@ -228,13 +230,23 @@ __global__ __launch_bounds__(256, 2) void attend_kernel(const AttendLaunch L)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const half8 a = *reinterpret_cast<const half8*>(a_rd + mt * 16 * S::kKRow + ks * 64);
-            c0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qreg[0][ks], c0[mt], 0, 0, 0);
-            c1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qreg[1][ks], c1[mt], 0, 0, 0);
+            c0[mt] = IN::mfma(a, qreg[0][ks], c0[mt]);
+            c1[mt] = IN::mfma(a, qreg[1][ks], c1[mt]);
         }
     }
-    half2v ph[2][kSlots16 / 2];
-    softmax20_probs<FAST_EXP>(c0, L.scale, L.round_logits, h, ph[0]);
-    softmax20_probs<FAST_EXP>(c1, L.scale, L.round_logits, h, ph[1]);
+    half2v ph[2][kSlots16 / 2];                              // packed 16-bit pairs: fp16 values, or bf16 bit patterns
+    if constexpr (IN::kBf16) {
+        float2v pf[kSlots16 / 2];
+        softmax20_probs_bf16(c0, L.scale, h, pf);
+#pragma unroll
+        for (int i = 0; i < kSlots16 / 2; ++i) ph[0][i] = __builtin_bit_cast(half2v, pack_bf16_exact(pf[i]));
+        softmax20_probs_bf16(c1, L.scale, h, pf);
+#pragma unroll
+        for (int i = 0; i < kSlots16 / 2; ++i) ph[1][i] = __builtin_bit_cast(half2v, pack_bf16_exact(pf[i]));
+    } else {
+        softmax20_probs<FAST_EXP>(c0, L.scale, L.round_logits, h, ph[0]);
+        softmax20_probs<FAST_EXP>(c1, L.scale, L.round_logits, h, ph[1]);
+    }
 
     // ---- tap: probabilities of the kept heads -> LDS tile [token][pixel] ------------------------------------------
     if (tap) {
@@ -251,6 +263,11 @@ __global__ __launch_bounds__(256, 2) void attend_kernel(const AttendLaunch L)
     const unsigned char* v_rd = vbuf + j * kVRow + h * 16;
     _Float16* out = reinterpret_cast<_Float16*>(L.out) + b * L.o_sb + hd * L.o_sh;
     const half2v z2 = {0, 0};
+    // bf16 output: the rounding instruction (v_cvt_pk_bf16_f32) only exists as inline asm, which gets no MFMA -> VALU wait
+    // states from the compiler; a multiply by an OPAQUE 1.0 in front is compiler-generated code (padded) and exact
+    float one = 1.0f;
+    asm volatile("" : "+v"(one));
+    const float2v one2 = {one, one};
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -268,10 +285,18 @@ __global__ __launch_bounds__(256, 2) void attend_kernel(const AttendLaunch L)
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb) {
                 const half8 a = *reinterpret_cast<const half8*>(v_rd + mt * 16 * kVRow + kb * 64);
-                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[kb], o, 0, 0, 0);
+                o = IN::mfma(a, pb[kb], o);
             }
-            const half2v lo = __builtin_convertvector(float2v{o[0], o[1]}, half2v);
-            const half2v hi = __builtin_convertvector(float2v{o[2], o[3]}, half2v);
+            half2v lo, hi;                                     // one rounding of the f32 product sums to the pipeline dtype
+            if constexpr (IN::kBf16) {
+                // compiler-generated moves first: this is the first VALU read of the MFMA result (wait states)
+                const float2v o01 = {o[0], o[1]}, o23 = {o[2], o[3]};
+                lo = __builtin_bit_cast(half2v, pack_bf16_pair(o01 * one2));
+                hi = __builtin_bit_cast(half2v, pack_bf16_pair(o23 * one2));
+            } else {
+                lo = __builtin_convertvector(float2v{o[0], o[1]}, half2v);
+                hi = __builtin_convertvector(float2v{o[2], o[3]}, half2v);
+            }
             if (px[g] < L.hw && 16 * mt + 4 * h < d)
                 *as_global_rw<half4v>(out + (int64_t)px[g] * L.o_sp + 16 * mt + 4 * h) = half4v{lo[0], lo[1], hi[0], hi[1]};
         }
@@ -287,7 +312,29 @@ __global__ __launch_bounds__(256, 2) void attend_kernel(const AttendLaunch L)
             if (row >= kTok || p0 + col >= L.hw) continue;
             const half8 pv = *reinterpret_cast<const half8*>(stage + row * kMfmaPixels + col);
             ACC_T* dst = acc + (size_t)row * L.hw + p0 + col;
-            if constexpr (sizeof(ACC_T) == 2) {
+            if constexpr (IN::kBf16) {
+                // bf16 probabilities (bit patterns in pv); sums in bf16 (heatmap.py:156 in bf16: f32 add of two bf16 values,
+                // one rounding) or f32
+                const ushort8 pb16 = __builtin_bit_cast(ushort8, pv);
+                float pf[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pf[i] = __uint_as_float((unsigned)pb16[i] << 16);
+                if constexpr (sizeof(ACC_T) == 2) {
+                    const ushort8 old = __builtin_bit_cast(ushort8, areg[a][0]);
+                    ushort8 sum;
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) {
+                        const unsigned r = pack_bf16_pair(float2v{__uint_as_float((unsigned)old[i] << 16) + pf[i],
+                                                                  __uint_as_float((unsigned)old[i + 1] << 16) + pf[i + 1]});
+                        sum[i] = (unsigned short)(r & 0xffffu);
+                        sum[i + 1] = (unsigned short)(r >> 16);
+                    }
+                    *as_global_rw<ushort8>(dst) = sum;
+                } else {
+                    *as_global_rw<float4v>(dst) = areg[a][0] + float4v{pf[0], pf[1], pf[2], pf[3]};
+                    *as_global_rw<float4v>(dst + 4) = areg[a][1] + float4v{pf[4], pf[5], pf[6], pf[7]};
+                }
+            } else if constexpr (sizeof(ACC_T) == 2) {
                 half8 sum = __builtin_bit_cast(half8, areg[a][0]);
                 sum += pv;                                               // heatmap.py:156 in fp16 (v_pk_add_f16)
                 *as_global_rw<half8>(dst) = sum;
@@ -302,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void attend_kernel(const AttendLaunch L)
 bool attend_d64_supported(int in_dtype, int head_dim, int tokens, const int64_t* strides, int n_strides, const void* const* ptrs,
                           int n_ptrs)
 {
-    if (in_dtype != 0 || head_dim < 8 || head_dim > 160 || head_dim % 8 != 0 || tokens != kTok) return false;
+    if ((in_dtype != 0 && in_dtype != 2) || head_dim < 8 || head_dim > 160 || head_dim % 8 != 0 || tokens != kTok) return false;
     for (int i = 0; i < n_strides; ++i)
         if (strides[i] % 8 != 0 || strides[i] < 0 || strides[i] >= ((int64_t)1 << 40)) return false;
     uintptr_t bits = 0;
@@ -310,36 +357,41 @@ bool attend_d64_supported(int in_dtype, int head_dim, int tokens, const int64_t*
     return (bits & 15) == 0;
 }
 
-template <typename ACC_T, bool FAST, int KS, int DT>
+template <typename IN, typename ACC_T, bool FAST, int KS, int DT>
 static hipError_t launch_attend_k(const AttendLaunch& L, hipStream_t stream, int grid, int* lds_out)
 {
     constexpr int lds = AttendShape<KS, DT>::kLds;
     *lds_out = lds;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attend_kernel<ACC_T, FAST, KS, DT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attend_kernel<IN, ACC_T, FAST, KS, DT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((attend_kernel<ACC_T, FAST, KS, DT>), dim3(grid), dim3(256), lds, stream, L);
+    hipLaunchKernelGGL((attend_kernel<IN, ACC_T, FAST, KS, DT>), dim3(grid), dim3(256), lds, stream, L);
     return hipGetLastError();
 }
 
-template <typename ACC_T, bool FAST>
+template <typename IN, typename ACC_T, bool FAST>
 static hipError_t launch_attend_shape(const AttendLaunch& L, hipStream_t stream, int grid, int* lds_out)
 {
-    if (L.head_dim <= 64) return launch_attend_k<ACC_T, FAST, 2, 4>(L, stream, grid, lds_out);
-    if (L.head_dim <= 96) return launch_attend_k<ACC_T, FAST, 3, 6>(L, stream, grid, lds_out);
-    return launch_attend_k<ACC_T, FAST, 5, 10>(L, stream, grid, lds_out);
+    if (L.head_dim <= 64) return launch_attend_k<IN, ACC_T, FAST, 2, 4>(L, stream, grid, lds_out);
+    if (L.head_dim <= 96) return launch_attend_k<IN, ACC_T, FAST, 3, 6>(L, stream, grid, lds_out);
+    return launch_attend_k<IN, ACC_T, FAST, 5, 10>(L, stream, grid, lds_out);
 }
 
-hipError_t launch_attend_d64(const AttendLaunch& L, int acc_dtype, int fast_exp, hipStream_t stream, int* grid_out, int* lds_out)
+hipError_t launch_attend_d64(const AttendLaunch& L, int in_dtype, int acc_dtype, int fast_exp, hipStream_t stream, int* grid_out, int* lds_out)
 {
     const int grid = L.wgs_per_xcd * 8;
     *grid_out = grid;
+    if (in_dtype == 2) {                                       // bf16 pipeline: bf16 or f32 sums, one softmax flavour
+        if (acc_dtype == 2) return launch_attend_shape<InBF16, bf16_t, true>(L, stream, grid, lds_out);
+        if (acc_dtype == 1) return launch_attend_shape<InBF16, float, true>(L, stream, grid, lds_out);
+        return hipErrorInvalidValue;
+    }
     if (acc_dtype == 0)
-        return fast_exp ? launch_attend_shape<_Float16, true>(L, stream, grid, lds_out) : launch_attend_shape<_Float16, false>(L, stream, grid, lds_out);
+        return fast_exp ? launch_attend_shape<InF16, _Float16, true>(L, stream, grid, lds_out) : launch_attend_shape<InF16, _Float16, false>(L, stream, grid, lds_out);
     if (acc_dtype == 1)
-        return fast_exp ? launch_attend_shape<float, true>(L, stream, grid, lds_out) : launch_attend_shape<float, false>(L, stream, grid, lds_out);
+        return fast_exp ? launch_attend_shape<InF16, float, true>(L, stream, grid, lds_out) : launch_attend_shape<InF16, float, false>(L, stream, grid, lds_out);
     return hipErrorInvalidValue;
 }
 

@@ -121,33 +121,26 @@ Reaper& reaper() {
     return *r;
 }
 
-struct LayerCache {
+// A layer's last validated call (tap or attend): shapes, dtype, device, parameters and the address of the descriptor the
+// engine built for it -- the C++ twin of daam_amd/engine.py::CallShape (set_cache / set_attend_cache copy one across).
+struct CallShape {
     bool valid = false;
     int64_t q_size[3] = {0, 0, 0};
     int64_t k_size[3] = {0, 0, 0};
     int dtype = -1;              // c10::ScalarType
     int device_type = -1;        // c10::DeviceType of the validated call (the engine only admits HIP devices)
     int device = -1;
-    long heads = 0, factor = 0;
+    long heads = 0, factor = 0;  // factor: taps only
     int round_logits = 1;
     double scale = 0.0;
-    uint64_t desc = 0;           // address of the layer's DaamQKDesc (owned by the engine)
+    uint64_t desc = 0;           // address of the DaamQKDesc / DaamAttendDesc (owned by the engine's CallShape)
 };
+using LayerCache = CallShape;
+using AttendCache = CallShape;
 
 // daam_attend (include/daam_hip.h), reached through the address the engine takes from the loaded library
 using AttendFn = int (*)(void* ctx, int layer, const void* q, const void* k, const void* v, void* out, const void* desc, int tap,
                          void* stream);
-
-struct AttendCache {             // a layer's validated attend() call: shapes, dtype, device, parameters, its DaamAttendDesc
-    bool valid = false;
-    int64_t q_size[3] = {0, 0, 0};
-    int64_t k_size[3] = {0, 0, 0};
-    int dtype = -1, device_type = -1, device = -1;
-    long heads = 0;
-    int round_logits = 1;
-    double scale = 0.0;
-    uint64_t desc = 0;
-};
 
 struct Recorder {
     PyObject_HEAD

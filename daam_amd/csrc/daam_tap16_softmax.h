@@ -38,25 +38,33 @@ struct InBF16 {                                              // operands travel 
     }
 };
 
-// f32 pair -> nearest bf16 (ties to even, one v_cvt_pk_bf16_f32), widened back to f32
-__device__ __forceinline__ float2v round_bf16_pair(float2v v) {
+// f32 pair -> nearest bf16 (ties to even, one v_cvt_pk_bf16_f32): packed (low half = first element) / widened back to f32
+__device__ __forceinline__ unsigned pack_bf16_pair(float2v v) {
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v[0]), "v"(v[1]));
+    return r;
+}
+__device__ __forceinline__ float2v round_bf16_pair(float2v v) {
+    const unsigned r = pack_bf16_pair(v);
     return float2v{__uint_as_float(r << 16), __uint_as_float(r & 0xffff0000u)};
+}
+// two f32 registers that hold bf16 values -> the packed pair (one v_perm_b32: the upper halves of both)
+__device__ __forceinline__ unsigned pack_bf16_exact(float2v v) {
+    return __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
 }
 
 // bf16 pipeline: logits = bf16(f32(q.k) * scale) -> f32 softmax -> bf16(p) -> acc = bf16(acc + p) (or f32 acc += p).
 // Same structure as the fast fp16 path below (token 0 as the reference point, true maximum only on overflow);
 // the values stay in f32 registers, so the exponent argument is a packed f32 FMA.
-template <typename ACC_T>
-__device__ __forceinline__ void softmax20_accumulate_bf16(const floatx4 (&c)[5], const TapLayer& lay, int h,
-                                                          float2v (&run)[kSlots16 / 2])
+// softmax20_probs_bf16: the lane's 20 probabilities, rounded to bf16, as f32 pairs (shared by the tap and by daam_attend,
+// whose fused sums are therefore bit-identical to the stand-alone tap's).
+__device__ __forceinline__ void softmax20_probs_bf16(const floatx4 (&c)[5], float scale, int h, float2v (&p)[kSlots16 / 2])
 {
     float2v x[kSlots16 / 2];
 #pragma unroll
     for (int mt = 0; mt < 5; ++mt) {
-        x[2 * mt] = round_bf16_pair(float2v{c[mt][0], c[mt][1]} * lay.scale);
-        x[2 * mt + 1] = round_bf16_pair(float2v{c[mt][2], c[mt][3]} * lay.scale);
+        x[2 * mt] = round_bf16_pair(float2v{c[mt][0], c[mt][1]} * scale);
+        x[2 * mt + 1] = round_bf16_pair(float2v{c[mt][2], c[mt][3]} * scale);
     }
     if (h == 3) {                                                       // tokens 77, 78, 79
         const float ninf = -__builtin_inff();
@@ -88,10 +96,19 @@ __device__ __forceinline__ void softmax20_accumulate_bf16(const floatx4 (&c)[5],
     }
     const float inv = __builtin_amdgcn_rcpf(tot);
 #pragma unroll
+    for (int i = 0; i < kSlots16 / 2; ++i) p[i] = round_bf16_pair(ev[i] * inv);   // probs.to(dtype)
+}
+
+template <typename ACC_T>
+__device__ __forceinline__ void softmax20_accumulate_bf16(const floatx4 (&c)[5], const TapLayer& lay, int h,
+                                                          float2v (&run)[kSlots16 / 2])
+{
+    float2v p[kSlots16 / 2];
+    softmax20_probs_bf16(c, lay.scale, h, p);
+#pragma unroll
     for (int i = 0; i < kSlots16 / 2; ++i) {
-        const float2v p = round_bf16_pair(ev[i] * inv);                   // probs.to(dtype)
-        if constexpr (sizeof(ACC_T) == 2) run[i] = round_bf16_pair(run[i] + p);   // heatmap.py:156 in bf16
-        else run[i] += p;
+        if constexpr (sizeof(ACC_T) == 2) run[i] = round_bf16_pair(run[i] + p[i]);   // heatmap.py:156 in bf16
+        else run[i] += p[i];
     }
 }
 

@@ -22,6 +22,28 @@ from . import _native as nat
 
 Key = Tuple[int, int, int]   # (factor, layer, head) -- daam/heatmap.py:145
 
+
+class CallShape:
+    """What a layer's last validated ``tap_qk`` / ``attend`` call looked like, with the descriptor built for it -- the
+    per-layer cache entry of the engine.  ``csrc/daam_fastpath.cpp`` mirrors it field by field in ``struct CallShape``
+    (``Recorder.set_cache`` / ``set_attend_cache`` copy an entry across)."""
+    __slots__ = ('q_shape', 'k_shape', 'dtype', 'heads', 'scale', 'round_logits', 'factor', 'desc_ref', 'desc', 'desc_addr',
+                 'q_numel', 'k_numel', 'held_bytes')
+
+    def __init__(self, query, key, heads, scale, round_logits, factor, desc):
+        self.q_shape, self.k_shape, self.dtype = query.shape, key.shape, query.dtype
+        self.heads, self.scale, self.round_logits, self.factor = heads, scale, round_logits, factor
+        self.desc = desc                                       # DaamQKDesc / DaamAttendDesc (kept alive here), or None
+        self.desc_ref = nat.byref(desc) if desc is not None else None
+        self.desc_addr = ctypes.addressof(desc) if desc is not None else 0
+        self.q_numel, self.k_numel = query.numel(), key.numel()
+        self.held_bytes = (self.q_numel + self.k_numel) * query.element_size()   # what a recorded call keeps alive
+
+    def same_call(self, query, key, heads, scale, round_logits, factor=None) -> bool:
+        return (self.q_shape == query.shape and self.k_shape == key.shape and self.dtype is query.dtype
+                and key.dtype is self.dtype and self.heads == heads and self.scale == scale
+                and self.round_logits == round_logits and (factor is None or self.factor == factor))
+
 # pipeline / running-sum dtypes the library knows (include/daam_hip.h).  fp16 runs on the MFMA kernels;
 # bf16 and fp32 on the any-shape kernels with the same rounding points.
 _DTYPE_CODE = {torch.float16: nat.DAAM_F16, torch.float32: nat.DAAM_F32, torch.bfloat16: nat.DAAM_BF16}
@@ -109,8 +131,8 @@ class HeatMapEngine:
         self._rec: List[tuple] = []                      # (layer, query, key, address of its DaamQKDesc)
         self._window = self.defer_steps                  # steps of one layer per launch
         self._cnt: List[int] = [0] * self.n_layers      # recorded steps per layer
-        self._qk_cache: List[Optional[tuple]] = [None] * self.n_layers
-        self._att_cache: List[Optional[tuple]] = [None] * self.n_layers   # attend(): per-layer call descriptors
+        self._qk_cache: List[Optional[CallShape]] = [None] * self.n_layers
+        self._att_cache: List[Optional[CallShape]] = [None] * self.n_layers   # attend(): per-layer call descriptors
         self._touched_flag: List[bool] = [False] * self.n_layers
         self._mask_cache: Dict[tuple, tuple] = {}        # finalize key masks per selection
         # deferred mode: the per-call bookkeeping runs in the C++ recorder (csrc/daam_fastpath.cpp) when
@@ -285,11 +307,10 @@ class HeatMapEngine:
         c = self._qk_cache[layer]
         cnt = self._cnt
         if (c is None or cnt[layer] == 0 or not self.defer_steps):
-            if (c is None or c[0] != query.shape or c[1] != key.shape or c[2] is not query.dtype
-                    or key.dtype is not c[2] or c[3] != heads or c[4] != scale or c[5] != round_logits
-                    or c[6] != factor or not query.is_contiguous() or not key.is_contiguous()):
+            if (c is None or not c.same_call(query, key, heads, scale, round_logits, factor)
+                    or not query.is_contiguous() or not key.is_contiguous()):
                 query, key, c = self._prepare_qk(layer, query, key, heads, scale, factor, round_logits)
-        elif (query.numel() != c[10] or key.numel() != c[11] or query.dtype is not c[2] or c[4] != scale
+        elif (query.numel() != c.q_numel or key.numel() != c.k_numel or query.dtype is not c.dtype or c.scale != scale
               or not query.is_contiguous() or not key.is_contiguous()):
             query, key, c = self._prepare_qk(layer, query, key, heads, scale, factor, round_logits)
         if self.defer_steps:
@@ -299,13 +320,13 @@ class HeatMapEngine:
                 self.flush()
                 n = 0
             cnt[layer] = n + 1
-            self._held += c[12]
+            self._held += c.held_bytes
             if self._check_versions:
-                self._rec.append((layer, query, key, c[9], query._version, key._version))
+                self._rec.append((layer, query, key, c.desc_addr, query._version, key._version))
             else:
-                self._rec.append((layer, query, key, c[9]))
+                self._rec.append((layer, query, key, c.desc_addr))
         else:
-            rc = self.lib.daam_tap_qk(self.ctx, layer, query.data_ptr(), key.data_ptr(), c[7], self.stream)
+            rc = self.lib.daam_tap_qk(self.ctx, layer, query.data_ptr(), key.data_ptr(), c.desc_ref, self.stream)
             if rc:
                 nat.check(rc)
         if not self._touched_flag[layer]:
@@ -317,16 +338,15 @@ class HeatMapEngine:
         layer's call descriptor, teaches the recorder the new call shape and records the tap."""
         f = self._fast
         c = self._qk_cache[layer] if 0 <= layer < self.n_layers else None
-        fresh = (c is None or c[0] != query.shape or c[1] != key.shape or c[2] is not query.dtype
-                 or key.dtype is not c[2] or c[3] != heads or c[4] != scale or c[5] != round_logits
-                 or c[6] != factor or not query.is_contiguous() or not key.is_contiguous())
+        fresh = (c is None or not c.same_call(query, key, heads, scale, round_logits, factor)
+                 or not query.is_contiguous() or not key.is_contiguous())
         if fresh:
             query, key, c = self._prepare_qk(layer, query, key, heads, scale, factor, round_logits)
         if f.full(layer):
             self.flush()
         if fresh:
-            f.set_cache(layer, query, key, int(heads), float(scale), int(factor), bool(round_logits), c[9])
-        f.record(layer, query, key, c[9])
+            f.set_cache(layer, query, key, int(heads), float(scale), int(factor), bool(round_logits), c.desc_addr)
+        f.record(layer, query, key, c.desc_addr)
         self._touch(layer)
 
     @property
@@ -383,9 +403,7 @@ class HeatMapEngine:
         # a shape change of a layer inside a deferred batch starts a new batch (the C side checks too)
         if self._pending(layer):
             self.flush()
-        entry = (query.shape, key.shape, query.dtype, heads, scale, round_logits, factor, nat.byref(desc), desc,
-                 ctypes.addressof(desc), query.numel(), key.numel(),
-                 (query.numel() + key.numel()) * query.element_size())
+        entry = CallShape(query, key, heads, scale, round_logits, factor, desc)
         self._qk_cache[layer] = entry
         return query, key, entry
 
@@ -394,29 +412,28 @@ class HeatMapEngine:
                factor: int, round_logits: bool = True, tapped: bool = True) -> Optional[torch.Tensor]:
         """``softmax(scale * Q K^T) V`` of one cross-attention call with the reference's rounding points
         (``get_attention_scores`` + ``bmm``, daam/trace.py:276,296-297) on ``daam_attend``; returns ``[B, hw, heads*d]``
-        ready for the output projection, or ``None`` when the call is not one the kernel takes (not fp16 / head_dim not a
-        multiple of 8 up to 160 / not 77 keys / not contiguous): the caller then uses the framework's attention and ``tap_qk``.
+        ready for the output projection, or ``None`` when the call is not one the kernel takes (not fp16 / bf16, head_dim not a
+        multiple of 8 up to 160, not 77 keys, not contiguous): the caller then uses the framework's attention and ``tap_qk``.
 
         ``tapped``: the call passes the reference's gate (trace.py:289).  On an immediate trace (``defer_steps=0``) the
         heat-map update happens inside the same kernel; on a deferred trace the kernel only attends and Q / K are
         recorded for the batched launch, exactly as ``tap_qk`` would."""
         a = self._att_cache[layer] if 0 <= layer < self.n_layers else None
-        if (a is None or a[0] != query.shape or a[1] != key.shape or a[2] is not query.dtype or a[3] != heads
-                or a[4] != scale or a[5] != round_logits):
+        if (a is None or a.q_shape != query.shape or a.k_shape != key.shape or a.dtype is not query.dtype or a.heads != heads
+                or a.scale != scale or a.round_logits != round_logits):
             a = self._prepare_attend(layer, query, key, value, heads, scale, round_logits)
-        if (a[6] is None or value.shape != a[1] or key.dtype is not a[2] or value.dtype is not a[2]
+        if (a.desc is None or value.shape != a.k_shape or key.dtype is not a.dtype or value.dtype is not a.dtype
                 or not (query.is_contiguous() and key.is_contiguous() and value.is_contiguous())
                 or ((query.requires_grad or key.requires_grad or value.requires_grad) and torch.is_grad_enabled())):
             return None                                                    # the kernel has no backward: leave autograd to torch
         fused_tap = tapped and not self.defer_steps
         if fused_tap:
             c = self._qk_cache[layer]
-            if (c is None or c[0] != query.shape or c[1] != key.shape or c[2] is not query.dtype or c[3] != heads
-                    or c[4] != scale or c[5] != round_logits or c[6] != factor):
+            if c is None or not c.same_call(query, key, heads, scale, round_logits, factor):
                 self._prepare_qk(layer, query, key, heads, scale, factor, round_logits)    # validates, configures the layer
         out = torch.empty_like(query)
         rc = self.lib.daam_attend(self.ctx, layer, query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(),
-                                  a[6], 1 if fused_tap else 0, self.stream)
+                                  a.desc_ref, 1 if fused_tap else 0, self.stream)
         if rc:
             if rc == nat.E_UNSUPPORTED:                    # e.g. a view whose data pointer is not 16-byte aligned
                 return None
@@ -432,27 +449,27 @@ class HeatMapEngine:
         if not 0 <= layer < self.n_layers:
             raise IndexError(f'layer {layer} out of range (trace has {self.n_layers} layers)')
         self._require_device(query)
-        ref = None
         desc = None
         d = query.shape[2] // heads if query.dim() == 3 and heads > 0 else 0
-        if (query.dtype is torch.float16 and query.dim() == 3 and key.dim() == 3 and key.shape[1] == self.tokens
+        # bf16 pipelines: the kernel rounds the logits to bf16 like the reference's baddbmm; upcast_attention (f32 logits) is left
+        # to the framework's attention
+        if ((query.dtype is torch.float16 or (query.dtype is torch.bfloat16 and round_logits))
+                and query.dim() == 3 and key.dim() == 3 and key.shape[1] == self.tokens
                 and d * heads == query.shape[2] and key.shape[2] == query.shape[2] and query.shape[0] == key.shape[0]
                 and d % 8 == 0 and 8 <= d <= 160 and query.shape[1] % 8 == 0):
             self._ensure_ctx(query.dtype)
-            if self.acc_dtype in (torch.float16, torch.float32):
+            if self.acc_dtype in (query.dtype, torch.float32):
                 b, hw, c = query.shape
-                qk = nat.QKDesc(in_dtype=nat.DAAM_F16, batch=b, heads=heads, hw=hw, tokens=self.tokens, head_dim=d,
+                qk = nat.QKDesc(in_dtype=_DTYPE_CODE[query.dtype], batch=b, heads=heads, hw=hw, tokens=self.tokens, head_dim=d,
                                 round_logits=1 if round_logits else 0, scale=float(scale),
                                 q_stride_b=hw * c, q_stride_h=d, q_stride_p=c,
                                 k_stride_b=self.tokens * c, k_stride_h=d, k_stride_t=c)
                 desc = nat.AttendDesc(qk=qk, v_stride_b=self.tokens * c, v_stride_h=d, v_stride_t=c,
                                       o_stride_b=hw * c, o_stride_h=d, o_stride_p=c)
-                ref = nat.byref(desc)
-        entry = (query.shape, key.shape, query.dtype, heads, scale, round_logits, ref, desc)
+        entry = CallShape(query, key, heads, scale, round_logits, 0, desc)
         self._att_cache[layer] = entry
         if self._fast is not None:
-            self._fast.set_attend_cache(layer, query, key, int(heads), float(scale), bool(round_logits),
-                                        ctypes.addressof(desc) if desc is not None else 0)
+            self._fast.set_attend_cache(layer, query, key, int(heads), float(scale), bool(round_logits), entry.desc_addr)
         return entry
 
     def _launch_stream(self):

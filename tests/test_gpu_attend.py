@@ -141,6 +141,64 @@ def test_attend_other_head_dims(head_dim, hw, accumulate):
     plain.close()
 
 
+@pytest.mark.parametrize('accumulate', ['exact', 'float32'])
+@pytest.mark.parametrize('head_dim,heads,hw', [(64, 10, 4096), (64, 20, 1024), (40, 8, 4096), (80, 8, 1024), (160, 8, 256), (64, 3, 576)])
+def test_attend_bf16_pipeline(head_dim, heads, hw, accumulate):
+    """bf16 pipelines (round 3): ``daam_attend`` on ``v_mfma_f32_16x16x32_bf16`` with the reference's bf16 rounding points
+    (bf16 logits, f32 softmax, bf16 probabilities, f32-accumulated value product rounded once to bf16).  Output against the
+    numpy oracle (``ho.attention_output(..., BF16)``) and the reference's torch ops in eager; the fused tap against the
+    stand-alone bf16 tap (bit-identical for head_dim <= 64, where both run the same tiling and softmax code) and against the
+    oracle's sums.  Tolerances: a bf16 logit of magnitude 8 .. 16 has an ulp of 2^-4, so a logit that the f32 summation order
+    moves across a rounding boundary (a few dozen of the millions per call) changes its probability by up to e^(2^-4) - 1 =
+    6.4 % -- and every probability of the row when it is the dominant one: outputs within one bf16 ulp for >= 99 % of the
+    elements and within 2^-4 of the largest everywhere; sums within 2^-3 |v| + one bf16 ulp, >= 99 % bit-equal."""
+    from oracle import heatmap_oracle as ho
+    scale = head_dim ** -0.5
+    fused, plain = _engine(accumulate=accumulate), _engine(accumulate=accumulate)
+    raw = ho.RawMaps(ho.BF16 if accumulate == 'exact' else np.float32)
+    for step in range(2):
+        q, k, v = _inputs(2, heads, hw, seed=11 * step + head_dim + heads, dtype=torch.bfloat16, head_dim=head_dim)
+        out = fused.attend(0, q, k, v, heads, scale, 1, True, tapped=True)
+        assert out is not None and out.shape == q.shape and out.dtype == torch.bfloat16
+        plain.tap_qk(0, q, k, heads, scale, 1, True)
+        qh, kh, vh = (_to_heads(t, heads).float().cpu().numpy() for t in (q, k, v))
+        want = torch.from_numpy(ho.batch_to_head_dim(ho.attention_output(qh, kh, vh, scale, ho.BF16), heads))
+        ref_scale = want.abs().max().item()
+        err = (out.float().cpu() - want).abs()
+        assert err.max().item() <= 2.0 ** -4 * ref_scale, err.max().item() / ref_scale
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(want.numpy()), 1e-30))) - 7)        # bf16: 8 significant bits
+        assert (err.numpy() <= ulp).mean() >= 0.99
+        want_eager, _ = _reference_eager(q, k, v, heads, scale)
+        err_eager = (out.float() - want_eager.float()).abs()
+        assert err_eager.max().item() <= 2.0 ** -4 * ref_scale
+        assert (err_eager <= 2.0 ** -7 * want_eager.float().abs().clamp_min(2.0 ** -20)).float().mean().item() >= 0.98
+        ho.tap(raw, 0, qh, kh, scale, latent_hw=hw, pipe_dtype=ho.BF16)
+    a, b = dict(fused.items()), dict(plain.items())
+    assert list(a) == list(b) and len(a) == heads
+    want_sums = np.stack([m for _, m in raw])
+    got = torch.stack([t for _, t in fused.items()]).float().cpu().numpy()
+    diff = np.abs(got - want_sums)
+    assert (diff - (2.0 ** -3 * np.abs(want_sums) + 2.0 ** -7 * np.maximum(1.0, np.abs(want_sums)))).max() <= 0
+    assert (diff > 0).mean() <= 0.01
+    for key in a:
+        assert a[key].dtype == b[key].dtype == (torch.bfloat16 if accumulate == 'exact' else torch.float32)
+        if head_dim <= 64:
+            assert torch.equal(a[key], b[key]), key
+        else:                                                    # head_dim > 64: the stand-alone bf16 tap is the any-shape kernel
+            d2 = (a[key].float() - b[key].float()).abs()
+            assert (d2 - (2.0 ** -3 * b[key].float().abs() + 2.0 ** -7)).max().item() <= 0 and (d2 > 0).float().mean().item() <= 0.01
+    fused.close()
+    plain.close()
+
+
+def test_attend_bf16_declines_unrounded_logits():
+    q, k, v = _inputs(2, 4, 256, seed=3, dtype=torch.bfloat16)
+    eng = _engine()
+    assert eng.attend(0, q, k, v, 4, 0.125, 1, False, tapped=False) is None      # upcast_attention: the framework's attention
+    assert eng.attend(0, q, k, v, 4, 0.125, 1, True, tapped=False) is not None
+    eng.close()
+
+
 def test_attend_unrounded_logits_and_general_scale():
     """``upcast_attention`` (logits stay f32) and a scale that is not a power of two take the exact-softmax variants."""
     q, k, v = _inputs(2, 4, 1024, seed=5)

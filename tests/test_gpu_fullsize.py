@@ -41,7 +41,7 @@ CASES = [
     ('sdxl2048_128x128_H4', 4, 128, 64, 20, 4096, 20, 64),    # SDXL-2048: hw = 16384, factor 0 (bicubic x0.5); 4 of the 10 heads
     # SDXL-2048 as BASELINE.json configs[4] runs it: all 10 heads, 100 steps, launches of 24 steps (what a 32 GiB byte
     # budget gives): every launch after the first reads the fp16 sums back (fresh = 0) -- 5 launches
-    ('sdxl2048_128x128_H10_100steps_5launches', 10, 128, 64, 100, 4096, 5, 24),
+    ('sdxl2048_128x128_H10_100steps_5launches', 10, 128, 64, 100, 4096, 25, 24),
     ('sd15_16x16_d160', 8, 16, 160, 50, 4096, 50, 64),        # SD-v1.5 deepest level
     ('sd15_32x32_d80', 8, 32, 80, 50, 4096, 50, 64),
     ('sd15_64x64_d40', 8, 64, 40, 50, 4096, 50, 64),          # SD-v1.5 outer level: head_dim 40 zero-padded to 64 (FULL64 = false)
@@ -100,8 +100,11 @@ def test_full_size_layer_50_steps_vs_oracle(name, heads, side, d, steps, latent_
     diff = np.abs(got - want)
     excess = diff - (2.0 ** -6 * np.abs(want) + 2 * _ulp16(np.maximum(np.abs(got), np.abs(want))))
     assert excess.max() <= 0, f'{name}: running sums off by {diff.flat[np.argmax(excess)]} at value {want.flat[np.argmax(excess)]}'
+    # a whole key: within 1 ulp of its largest sum; 2 when query sets recur (a probability that differs by one fp16 ulp then
+    # differs in every recurrence, and the two fp16 accumulation chains can round apart at more than one of their steps)
+    key_ulps = 1 if n_q >= steps else 2
     for h in range(heads):
-        assert diff[h].max() <= _ulp16(np.asarray(want[h].max())) + 1e-12, f'{name}: head {h}'
+        assert diff[h].max() <= key_ulps * _ulp16(np.asarray(want[h].max())) + 1e-12, f'{name}: head {h}'
     assert (diff > 0).mean() <= 0.01
     np.testing.assert_allclose(got.sum(1), steps, atol=steps * 77 * 2.0 ** -11)
 

@@ -268,7 +268,7 @@ def test_cxx_recorder_steady_state(fake_engine):
     assert list((ctypes.c_uint64 * n).from_address(qa)) == [q[i].data_ptr() for i in (2, 0, 3, 1, 2, 0)]
     assert list((ctypes.c_uint64 * n).from_address(ka)) == [k[i].data_ptr() for i in (2, 0, 3, 1, 2, 0)]
     descs = list((ctypes.c_uint64 * n).from_address(da))
-    assert descs[0] == eng._qk_cache[1][9] and descs[1] == eng._qk_cache[0][9]
+    assert descs[0] == eng._qk_cache[1].desc_addr and descs[1] == eng._qk_cache[0].desc_addr
     # the window (3 steps) is full: the next call launches first
     eng.tap_qk(1, q[2], k[2], 2, 0.35, 1)
     assert lib.names().count('daam_tap_flush') == 1 and eng.pending_taps == 1 and slow == [1, 0]

@@ -26,7 +26,8 @@ def find(d, suffix):
 def short(name):
     if 'daam' not in name:
         return None
-    for k in ('tap_d64_kernel', 'tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_down2_kernel',
+    for k in ('tap_d64_kernel', 'tap_wide_kernel', 'tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'attend_kernel', 'finalize_up32_pipe_kernel',
+              'finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_down2_kernel',
               'finalize_up_kernel', 'finalize_same_kernel', 'finalize_kernel', 'normalize_kernel', 'word_'):
         if k in name:
             return k
@@ -71,7 +72,7 @@ def main():
         tpath = os.path.join(a.out, 'hbm_traffic.json')
         traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
         rec = {}
-        for kern, field in (('tap_d64_kernel', 'tap'), ('tap_mfma_kernel', 'tap'),
+        for kern, field in (('tap_d64_kernel', 'tap'), ('tap_mfma_kernel', 'tap'), ('finalize_up32_pipe_kernel', 'finalize_pipe'),
                             ('finalize_up32_same_kernel', 'finalize_pair'), ('finalize_up32_mfma_kernel', 'finalize_up'),
                             ('finalize_same_kernel', 'finalize_same')):
             cs = pmc.get(kern, {})
@@ -106,7 +107,7 @@ def main():
         def upper_median(v):
             v = sorted(v)
             return statistics.median(v[len(v) // 2:])
-        tap_names = [k for k in ('tap_d64_kernel', 'tap_mfma_kernel') if k in pmc and 'SQ_ACTIVE_INST_VALU' in pmc[k]]
+        tap_names = [k for k in ('tap_d64_kernel', 'tap_wide_kernel', 'tap_mfma_kernel') if k in pmc and 'SQ_ACTIVE_INST_VALU' in pmc[k]]
         if tap_names:
             # a flush may run several tap kernels side by side (SD-v1.5): their work adds up on the same SIMDs
             w['tap_valu_busy_cycles_per_simd'] = round(sum(upper_median(pmc[k]['SQ_ACTIVE_INST_VALU']) for k in tap_names) * 4 / 1024, 1)
@@ -115,7 +116,7 @@ def main():
                 w['tap_mfma_per_simd'] = round(sum(upper_median(pmc[k]['SQ_INSTS_MFMA']) for k in tap_names) / 1024, 1)
             if all('SQ_VALU_MFMA_BUSY_CYCLES' in pmc[k] for k in tap_names):
                 w['tap_mfma_busy_cycles_per_simd'] = round(sum(upper_median(pmc[k]['SQ_VALU_MFMA_BUSY_CYCLES']) for k in tap_names) / 1024, 1)
-        fin_names = [k for k in ('finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_same_kernel', 'finalize_down2_kernel', 'finalize_up_kernel',
+        fin_names = [k for k in ('finalize_up32_pipe_kernel', 'finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_same_kernel', 'finalize_down2_kernel', 'finalize_up_kernel',
                                  'finalize_kernel') if k in pmc and 'SQ_ACTIVE_INST_VALU' in pmc[k]]
         if fin_names:
             w['finalize_valu_busy_cycles_per_simd'] = round(sum(upper_median(pmc[k]['SQ_ACTIVE_INST_VALU']) for k in fin_names) * 4 / 1024, 1)
