@@ -189,6 +189,7 @@ struct DaamCtx {
     void* d_up32_ops = nullptr;        // finalize_up32_mfma_kernel operands of the 32 -> 64 table (see build_up32_ops)
     int up32_tab = -1;
     int no_mfma_finalize = 0;
+    int no_fold_same = 0;             // debugging / A-B: the same-size class as its own kernel beside the pipelined one
     int no_pipe_finalize = 0;         // debugging / A-B: the round-2 x2 MFMA kernel instead of the software-pipelined one
     void* d_zero_planes = nullptr;    // [tokens][32 x 32] fp16 zeros: padding keys of the pipelined x2 finalize
     int no_paired_finalize = 0;       // debugging / A-B: same-size and x2 class as two launches
@@ -356,6 +357,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->force_generic = fg && fg[0] == '1';
     const char* nm = getenv("DAAM_NO_MFMA_FINALIZE");
     c->no_mfma_finalize = nm && nm[0] == '1';
+    const char* nfs = getenv("DAAM_NO_FOLD_SAME");
+    c->no_fold_same = nfs && nfs[0] == '1';
     const char* npp = getenv("DAAM_NO_PIPE_FINALIZE");
     c->no_pipe_finalize = npp && npp[0] == '1';
     const char* npf = getenv("DAAM_NO_PAIRED_FINALIZE");
@@ -1005,9 +1008,15 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         pipe_nk = std::max(4, (per + 1) & ~1);
         pipe_stride = (pipe_nk + finalize_pipe_ring() + 2) & ~1;
     }
+    // The same-size (64 x 64) keys ride along in the pipelined kernel (every wave adds its share of them to its accumulators
+    // before the x2 loop) unless they outnumber the x2 keys 2 : 1 -- then they keep their own streaming kernel.
+    const bool fold_same = pipe_up && !keys[0].empty() && c->out_side == 64 && keys[0].size() <= 2 * keys[1].size() &&
+                           !c->no_fold_same;
+    const int same_per = fold_same ? ((int)keys[0].size() + pipe_chunks - 1) / pipe_chunks : 0;
     size_t off = 0;
     const size_t key_bytes = ((size_t)total * sizeof(FinKey) + 63) & ~size_t(63);
-    const size_t bytes = key_bytes + (size_t)pipe_chunks * pipe_stride * sizeof(unsigned long long);
+    const size_t ptr_bytes = (size_t)pipe_chunks * pipe_stride * sizeof(unsigned long long);
+    const size_t bytes = key_bytes + ptr_bytes + (size_t)pipe_chunks * same_per * sizeof(unsigned long long);
     HIP_TRY(c->ring.alloc(bytes, &off));
     {
         FinKey* dst = reinterpret_cast<FinKey*>(c->ring.host + off);
@@ -1020,6 +1029,12 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
                 for (int j = 0; j < pipe_stride; ++j) {
                     const int k = ch * per + j;
                     pt[(size_t)ch * pipe_stride + j] = (j < per && k < n) ? reinterpret_cast<unsigned long long>(keys[1][k].base) : zero;
+                }
+            unsigned long long* st = pt + (size_t)pipe_chunks * pipe_stride;
+            for (int ch = 0; ch < pipe_chunks; ++ch)
+                for (int j = 0; j < same_per; ++j) {
+                    const size_t k = (size_t)ch * same_per + j;
+                    st[(size_t)ch * same_per + j] = k < keys[0].size() ? reinterpret_cast<unsigned long long>(keys[0][k].base) : 0ull;
                 }
         }
     }
@@ -1101,9 +1116,16 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     // registers: their waves fit beside the two heavy waves of a SIMD) goes to an auxiliary stream forked from / joined to the
     // caller's by events, launched FIRST -- SDXL-1024: 63 MB of same-size planes stream under 158 MB of x2 planes; SD-v1.5:
     // three classes side by side instead of three serial launches.
+    if (fold_same) have[0] = false;                            // done inside the pipelined kernel
     int n_classes = 0;
     for (int cls = 0; cls < kClasses; ++cls) n_classes += have[cls] ? 1 : 0;
-    bool fork = pipe_up && n_classes > 1 && n_classes <= DaamCtx::kAux + 1 && !c->no_side_stream;
+    // (an event fork / join costs ~15 us of queue latency per finalize call: only worth it for a side class of tens of MB --
+    // SD-v1.5's 1.6 MB x4 class runs 10 us faster serially behind the pipelined kernel)
+    size_t side_bytes = 0;
+    for (int cls = 0; cls < kClasses; ++cls)
+        if (have[cls] && cls != 1)
+            for (auto& k : keys[cls]) side_bytes += (size_t)c->tokens * k.side * k.side * acc_elem(c->acc_dtype);
+    bool fork = pipe_up && n_classes > 1 && n_classes <= DaamCtx::kAux + 1 && !c->no_side_stream && side_bytes >= ((size_t)16 << 20);
     if (fork) {
         hipError_t ae = ensure_aux(c);
         if (ae != hipSuccess || hipEventRecord(c->aux_fork, s) != hipSuccess) fork = false;    // serial launches still correct
@@ -1114,6 +1136,8 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         if (cls == 1 && pipe_up) {
             FinPipeLaunch P;
             P.key_ptrs = reinterpret_cast<const unsigned long long*>(c->ring.dev + off + key_bytes);
+            P.same_ptrs = fold_same ? reinterpret_cast<const unsigned long long*>(c->ring.dev + off + key_bytes + ptr_bytes) : nullptr;
+            P.same_per = same_per;
             P.mfma_ops = c->d_up32_ops;
             P.out = out;
             P.n_chunks = pipe_chunks;

@@ -115,6 +115,8 @@ struct FinLaunch {
 // the same for every chunk; the ring prefetches kPipeRing + 1 entries past nk_pad, which must be valid pointers too).
 struct FinPipeLaunch {
     const unsigned long long* key_ptrs;
+    const unsigned long long* same_ptrs;   // [n_chunks][same_per] planes of token 0 of the 64 x 64 keys folded in (0 = padding), or NULL
+    int32_t same_per;
     const void* mfma_ops;   // as FinLaunch::mfma_ops
     float* out;             // [tokens, 64, 64]
     int32_t n_chunks;

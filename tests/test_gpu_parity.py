@@ -268,25 +268,29 @@ def test_finalize_many_x2_keys(n_keys, path, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize('fold', ['fold', 'nofold'])
 @pytest.mark.parametrize('n_keys', [1, 2, 3, 5, 8, 13, 27, 104, 105, 1000, 1001])
-def test_finalize_pipe_key_counts(n_keys, monkeypatch):
+def test_finalize_pipe_key_counts(n_keys, fold, monkeypatch):
     """The software-pipelined x2 kernel walks a pointer table padded with all-zero planes to an even length >= 4 per chunk:
     key counts around every padding / chunking boundary (1 key = 3 padding planes; 13 chunks from 104 keys on; odd shares),
-    with a same-size layer beside it (second stream).  Key i = plane set (i mod 27) scaled by 2^-(i mod 3)."""
+    with a same-size layer (two or five 64 x 64 keys) whose keys ride along in the same kernel (``fold``) or run as their own
+    kernel on a second stream (``nofold``).  Key i = plane set (i mod 27) scaled by 2^-(i mod 3)."""
     monkeypatch.setenv('DAAM_NO_MFMA_FINALIZE', '0')
     monkeypatch.setenv('DAAM_NO_PIPE_FINALIZE', '0')
+    monkeypatch.setenv('DAAM_NO_FOLD_SAME', '1' if fold == 'nofold' else '0')   # same-size keys inside the pipelined kernel / beside it
     rng = np.random.default_rng(1000 + n_keys)
     base_n, side = 27, 32
     base = (rng.standard_normal((base_n, side * side, 77)) * 3).astype(np.float16)
     per_key = np.stack([ho.global_heat_map([((2, 0, 0), ho.unravel(np.concatenate([base[i:i + 1]] * 2))[0])], 4096)
                         for i in range(base_n)]).astype(np.float64)
     scales = 2.0 ** -(np.arange(n_keys) % 3)
-    same = (rng.standard_normal((2 * 2, 64 * 64, 77)) * 3).astype(np.float16)             # layer 1: two 64 x 64 keys
-    same_maps = [ho.global_heat_map([((1, 1, h), ho.unravel(same)[h])], 4096).astype(np.float64) for h in range(2)]
+    n_same = 5 if n_keys >= 8 else 2                                                        # layer 1: 64 x 64 keys
+    same = (rng.standard_normal((2 * n_same, 64 * 64, 77)) * 3).astype(np.float16)
+    same_maps = [ho.global_heat_map([((1, 1, h), ho.unravel(same)[h])], 4096).astype(np.float64) for h in range(n_same)]
     want = sum(same_maps)
     for i in range(n_keys):
         want = want + scales[i] * per_key[i % base_n]
-    want /= n_keys + 2
+    want /= n_keys + n_same
     eng = _engine(n_layers=2, accumulate='exact')
     bd = torch.from_numpy(base).to(DEV)
     idx = torch.arange(n_keys, device=DEV)
@@ -464,7 +468,8 @@ def test_trace_api_matches_reference_golden(golden_case, tap, defer, tmp_path):
 
 @pytest.mark.parametrize('env', [dict(DAAM_STRICT_EXP='1'), dict(DAAM_NO_D64='1'), dict(DAAM_NO_D64='1', DAAM_STRICT_EXP='1'),
                                  dict(DAAM_FORCE_GENERIC='1'), dict(DAAM_NO_PIPE_FINALIZE='1'),
-                                 dict(DAAM_NO_PIPE_FINALIZE='1', DAAM_NO_PAIRED_FINALIZE='1'), dict(DAAM_NO_SIDE_STREAM='1')])
+                                 dict(DAAM_NO_PIPE_FINALIZE='1', DAAM_NO_PAIRED_FINALIZE='1'), dict(DAAM_NO_SIDE_STREAM='1'),
+                                 dict(DAAM_NO_FOLD_SAME='1')])
 def test_optional_kernel_paths_keep_parity(env, monkeypatch):
     """The opt-in / fallback kernel variants (compensated-exp softmax, the 32x32-tile MFMA kernel instead of the
     head_dim-64 one, the any-shape kernels) stay within the same tolerances on an SDXL-shaped fp16 case (head_dim 64)."""

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Generates daam_amd/csrc/daam_finalize_pipe_asm.inc: the software-pipelined main loop of the x2 (32 -> 64) finalize on the
-matrix cores as ONE hand-scheduled inline-asm statement (fixed physical registers, counted waits, LDS-DMA plane ring).
+"""Generates daam_amd/csrc/daam_finalize_pipe_prefill.inc and daam_finalize_pipe_asm.inc: the software-pipelined main loop of the
+x2 (32 -> 64) finalize on the matrix cores as hand-scheduled inline asm (fixed physical registers, counted waits, LDS-DMA plane
+ring): statement 1 starts the ring's first R planes, statement 2 is the pipeline (the kernel runs its same-size keys between the
+two, under the latency of the prefill).
 
     python tools/gen_fin_pipe.py            # rewrites the .inc (committed next to this script's output)
 
@@ -16,12 +18,20 @@ ties vdst = srcC), and an asm statement gets no hazard padding from it: the dist
 (cdna_hip_programming.md section 5.7):
   * MFMA result -> VALU read: >= 2 later MFMAs of the in-order matrix pipe issued in between (>= 64 cycles; 12 states needed);
   * VALU write -> MFMA operand: >= 2 instructions in between;  T is rewritten by A(i+2) only after every B(i+1) instruction;
-  * LDS-DMA -> ds_read: the issuing wave's counted vmcnt (the ring is wave-private: no barrier);  ds_read -> MFMA: lgkmcnt(0);
-  * ring slot reuse: the DMA into slot (i+1) % R is issued after the lgkmcnt(0) that retired plane i+1's reads.
+  * the ring belongs to the WORKGROUP: each of its two waves (the two 32-column output halves) fetches one 1 KiB half of every
+    plane and both read all of it -- a plane crosses L2 -> LDS once (with wave-private rings the duplicate fetches doubled the
+    kernel's traffic to 6.7 TB/s and bounded it).  LDS-DMA -> ds_read: each wave's counted vmcnt, THEN s_barrier (the partner's
+    half), then the reads;  ds_read -> MFMA: lgkmcnt(0);
+  * ring slot reuse: the DMA into slot (i+1) % R is issued after this iteration's barrier, which both waves pass only after the
+    lgkmcnt(0) that retired their reads of plane i+1.
 """
 import os
 
-R = 8                     # ring slots (planes) per wave, 2 KiB each
+import sys
+
+R = int(os.environ.get('DAAM_PIPE_RING', '16'))     # ring slots (planes) per workgroup, 2 KiB each: 8 or 16 (the pointers of the first R planes
+                                                     # come in by s_load_dwordx16)
+assert R in (8, 16)
 SLOT = 2048
 # ---- register map --------------------------------------------------------------------------------------------------
 WX = (0, 4)               # B operands of pass 1 (4 VGPRs each)
@@ -31,11 +41,11 @@ T = 32                    # 16
 def BSET(s): return 48 + 16 * s          # bhi0 +0, bhi1 +4, blo0 +8, blo1 +12
 def OSET(s): return 80 + 32 * s          # o0 +0, o1 +16
 def ASET(s): return 144 + 32 * s         # acc0 +0, acc1 +16
-GOFF_LO, GOFF_HI, LDS_RD, LDS_TMP = 208, 209, 210, 211
+GOFF, LDS_RD, LDS_TMP = 208, 210, 211          # GOFF: this wave's half of a plane (tok * 2048 + nt * 1024 + lane * 16)
 S_KEYS = '36:37'
 S_KOFF, S_TRIPS, S_RING, S_RDSLOT, S_DMASLOT, S_M0SAVE = 38, 39, 42, 43, 44, 47
 S_BASE = '40:41'
-S_PRE = 48                # s[48:63]: the first 8 plane pointers
+S_PRE = 48                # s[48:63] (R = 16: .. s79): the pointers of the first R planes
 
 def vr(b, n): return f'v[{b}:{b + n - 1}]'
 def mfma(d, a, b, c): return f'v_mfma_f32_32x32x16_f16 {vr(d, 16)}, {vr(a, 4)}, {vr(b, 4)}, ' + ('0' if c is None else vr(c, 16))
@@ -64,16 +74,16 @@ def stage_B(s):
     return L
 
 def dma(base):
-    """plane -> ring slot S_DMASLOT (two 1 KiB pieces), then advance the slot"""
-    return [f's_add_u32 m0, s{S_RING}, s{S_DMASLOT}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF_LO}, s[{base}]',
-            's_add_u32 m0, m0, 0x400', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF_HI}, s[{base}]',
+    """this wave's half of a plane -> ring slot S_DMASLOT (S_RING already points at the wave's half of slot 0), advance the slot"""
+    return [f's_add_u32 m0, s{S_RING}, s{S_DMASLOT}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF}, s[{base}]',
             f's_add_u32 s{S_DMASLOT}, s{S_DMASLOT}, {SLOT}', f's_and_b32 s{S_DMASLOT}, s{S_DMASLOT}, {R * SLOT - 1}']
 
 def next_key():
     return [f's_load_dwordx2 s[{S_BASE}], s[{S_KEYS}], s{S_KOFF}', f's_add_u32 s{S_KOFF}, s{S_KOFF}, 8']
 
 def read_plane():
-    return [f'v_add_u32 v{LDS_TMP}, s{S_RDSLOT}, v{LDS_RD}', f'ds_read_b128 {vr(P[0], 4)}, v{LDS_TMP}',
+    """after the caller's vmcnt wait: the partner's half has landed once both waves are past the barrier"""
+    return ['s_barrier', f'v_add_u32 v{LDS_TMP}, s{S_RDSLOT}, v{LDS_RD}', f'ds_read_b128 {vr(P[0], 4)}, v{LDS_TMP}',
             f'ds_read_b128 {vr(P[1], 4)}, v{LDS_TMP} offset:32',
             f's_add_u32 s{S_RDSLOT}, s{S_RDSLOT}, {SLOT}', f's_and_b32 s{S_RDSLOT}, s{S_RDSLOT}, {R * SLOT - 1}']
 
@@ -83,7 +93,7 @@ def iteration(pi, do_c=True, do_d=True, do_b=True, do_a=True, do_dma=True):
     """one pipeline step for parity pi: C(i) | D(i-1) on set 1-pi | B(i+1) -> set 1-pi | A(i+2)"""
     L = []
     if do_a:
-        L += [f's_waitcnt vmcnt({2 * (R - 2)})'] + read_plane()
+        L += [f's_waitcnt vmcnt({R - 2})'] + read_plane()
     m = (stage_C(pi) if do_c else []) + (stage_A() if do_a else [])
     d = stage_D(1 - pi) if do_d else []
     b = stage_B(1 - pi) if do_b else []
@@ -100,25 +110,34 @@ def iteration(pi, do_c=True, do_d=True, do_b=True, do_a=True, do_dma=True):
         L += valu[k:k + n]
         k += n
         if do_dma and do_c and gi == 5:
-            L += ['s_waitcnt lgkmcnt(0)'] + dma(S_BASE)[:3]
+            L += ['s_waitcnt lgkmcnt(0)'] + dma(S_BASE)
         if do_dma and do_c and gi == 6:
-            L += dma(S_BASE)[3:] + next_key()
+            L += next_key()
     L += valu[k:]
     return L
 
+def build_prefill():
+    """statement 1: the ring's first R planes (this wave's halves) are on their way; nothing is waited for"""
+    L = [f's_mov_b32 s{S_M0SAVE}, m0', f's_load_dwordx16 s[{S_PRE}:{S_PRE + 15}], s[{S_KEYS}], 0x0']
+    if R == 16:
+        L += [f's_load_dwordx16 s[{S_PRE + 16}:{S_PRE + 31}], s[{S_KEYS}], 0x40']
+    L += ['s_waitcnt lgkmcnt(0)']
+    for q in range(R):
+        L += [f's_add_u32 m0, s{S_RING}, 0x{q * SLOT:x}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF}, s[{S_PRE + 2 * q}:{S_PRE + 2 * q + 1}]']
+    L += [f's_mov_b32 m0, s{S_M0SAVE}']
+    return L
+
+
 def build():
     L = [f's_mov_b32 s{S_M0SAVE}, m0']
-    # running sums and the o set the first D reads: zero
-    L += [f'v_mov_b32 v{r}, 0' for r in list(range(ASET(0), ASET(0) + 64)) + list(range(OSET(1), OSET(1) + 32))]
-    L += [f's_load_dwordx16 s[{S_PRE}:{S_PRE + 15}], s[{S_KEYS}], 0x0', f's_load_dwordx2 s[{S_BASE}], s[{S_KEYS}], 0x{8 * R:x}',
-          f's_mov_b32 s{S_KOFF}, 0x{8 * (R + 1):x}', f's_mov_b32 s{S_RDSLOT}, 0', f's_mov_b32 s{S_DMASLOT}, 0', 's_waitcnt lgkmcnt(0)']
-    for q in range(R):                                                        # prefill the ring: planes 0 .. R-1
-        L += [f's_add_u32 m0, s{S_RING}, 0x{q * SLOT:x}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF_LO}, s[{S_PRE + 2 * q}:{S_PRE + 2 * q + 1}]',
-              f's_add_u32 m0, s{S_RING}, 0x{q * SLOT + 1024:x}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF_HI}, s[{S_PRE + 2 * q}:{S_PRE + 2 * q + 1}]']
+    # the odd planes' running sums and the o set the first D reads: zero (the even planes' sums come in: the same-size keys)
+    L += [f'v_mov_b32 v{r}, 0' for r in list(range(ASET(1), ASET(1) + 32)) + list(range(OSET(1), OSET(1) + 32))]
+    L += [f's_load_dwordx2 s[{S_BASE}], s[{S_KEYS}], 0x{8 * R:x}',
+          f's_mov_b32 s{S_KOFF}, 0x{8 * (R + 1):x}', f's_mov_b32 s{S_RDSLOT}, 0', f's_mov_b32 s{S_DMASLOT}, 0']
     # i = -2: A(0)
-    L += [f's_waitcnt vmcnt({2 * (R - 1)})'] + read_plane() + ['s_waitcnt lgkmcnt(0)'] + stage_A()
+    L += [f's_waitcnt vmcnt({R - 1})'] + read_plane() + ['s_waitcnt lgkmcnt(0)'] + stage_A()
     # i = -1: B(0) -> set 0, A(1); DMA of plane R into slot 0
-    L += [f's_waitcnt vmcnt({2 * (R - 2)})'] + read_plane()
+    L += [f's_waitcnt vmcnt({R - 2})'] + read_plane()
     L += ['s_nop 15', 's_nop 15']                                             # T(0): the 2 MFMAs above -> first VALU read
     L += stage_B(0)
     L += ['s_waitcnt lgkmcnt(0)'] + stage_A() + dma(S_BASE) + next_key()
@@ -132,26 +151,40 @@ def build():
     L += ['s_waitcnt vmcnt(0)', f's_mov_b32 m0, s{S_M0SAVE}']
     return L
 
-def main():
-    lines = build()
-    used_v = sorted(set(range(P[0], GOFF_LO)) - set(range(ASET(0), ASET(0) + 64))) + [LDS_TMP]
-    clob = [f'"v{r}"' for r in used_v] + [f'"s{r}"' for r in [S_KOFF, 40, 41, S_RDSLOT, S_DMASLOT, 45, S_M0SAVE] + list(range(S_PRE, S_PRE + 16))]
-    clob += ['"memory"', '"scc"', '"vcc"']
-    out = ['// GENERATED by tools/gen_fin_pipe.py -- do not edit; the schedule and its hazard distances are documented there.',
-           '// One asm statement: prologue, software-pipelined loop over the planes of this wave, drain.',
-           f'// {sum(1 for l in lines if l.startswith("v_mfma"))} MFMA + {sum(1 for l in lines if l.startswith("v_") and not l.startswith("v_mfma"))} VALU statements in the text; ring of {R} planes.',
-           'asm volatile(']
+
+def emit(path, header, lines, outs, ins, clob):
+    out = header + ['asm volatile(']
     for l in lines:
         out.append(f'    "{l}\\n\\t"')
-    out.append('    : "={v[144:159]}"(accA0), "={v[160:175]}"(accA1), "={v[176:191]}"(accB0), "={v[192:207]}"(accB1), "+{s39}"(trips)')
-    out.append('    : "{v[0:3]}"(wx0), "{v[4:7]}"(wx1), "{v[8:11]}"(wy00), "{v[12:15]}"(wy01), "{v[16:19]}"(wy10), "{v[20:23]}"(wy11),')
-    out.append('      "{v208}"(goff_lo), "{v209}"(goff_hi), "{v210}"(lds_rd), "{s[36:37]}"(key_ptrs), "{s42}"(ring_base)')
+    out.append('    : ' + outs)
+    out.append('    : ' + ins)
     out.append('    : ' + ', '.join(clob) + ');')
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'daam_amd', 'csrc', 'daam_finalize_pipe_asm.inc')
     open(path, 'w').write('\n'.join(out) + '\n')
+
+
+def main():
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'daam_amd', 'csrc')
+    pre = build_prefill()
+    emit(os.path.join(here, f'daam_finalize_pipe_prefill_r{R}.inc'),
+         ['// GENERATED by tools/gen_fin_pipe.py -- do not edit.  Statement 1: LDS-DMA of the first planes of the ring (this wave\'s halves).'],
+         pre, '', '"{v208}"(goff), "{s[36:37]}"(key_ptrs), "{s42}"(ring_half)',
+         [f'"s{r}"' for r in [S_M0SAVE] + list(range(S_PRE, S_PRE + 2 * R))] + ['"memory"', '"scc"'])
+    lines = build()
+    used_v = sorted(set(range(P[0], GOFF)) - set(range(ASET(0), ASET(0) + 64))) + [LDS_TMP]
+    clob = [f'"v{r}"' for r in used_v] + [f'"s{r}"' for r in [S_KOFF, 40, 41, S_RDSLOT, S_DMASLOT, 45, S_M0SAVE]]
+    clob += ['"memory"', '"scc"', '"vcc"']
+    emit(os.path.join(here, f'daam_finalize_pipe_asm_r{R}.inc'),
+         ['// GENERATED by tools/gen_fin_pipe.py -- do not edit; the schedule and its hazard distances are documented there.',
+          '// Statement 2: software-pipelined loop over the planes of this workgroup\'s chunk (the ring was started by statement 1), drain.',
+          f'// {sum(1 for l in lines if l.startswith("v_mfma"))} MFMA + {sum(1 for l in lines if l.startswith("v_") and not l.startswith("v_mfma"))} VALU statements in the text; ring of {R} planes per workgroup.'],
+         lines,
+         '"+{v[144:159]}"(accA0), "+{v[160:175]}"(accA1), "={v[176:191]}"(accB0), "={v[192:207]}"(accB1), "+{s39}"(trips)',
+         '"{v[0:3]}"(wx0), "{v[4:7]}"(wx1), "{v[8:11]}"(wy00), "{v[12:15]}"(wy01), "{v[16:19]}"(wy10), "{v[20:23]}"(wy11),\n'
+         '      "{v208}"(goff), "{v210}"(lds_rd), "{s[36:37]}"(key_ptrs), "{s42}"(ring_half)', clob)
     per_iter = iteration(0)
-    print('wrote', path, len(lines), 'instructions;', 'steady iteration:', len(per_iter), 'instructions,',
+    print('wrote', here, len(pre), '+', len(lines), 'instructions;', 'steady iteration:', len(per_iter), 'instructions,',
           sum(1 for l in per_iter if l.startswith('v_mfma')), 'MFMA')
+
 
 if __name__ == '__main__':
     main()

@@ -1,0 +1,47 @@
+"""Debug: per-wave phase timestamps of finalize_up32_pipe_kernel + HIP-event times of finalize for several key selections.
+Needs a library built with -DDAAM_PIPE_TIMING (daam_amd.build.build_variant(out, ['-DDAAM_PIPE_TIMING']));
+    DAAM_HIP_LIB=X.so python tools/pipe_timing.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from daam_amd.engine import HeatMapEngine
+from daam_amd import _native as nat
+layers = bench.topology('sdxl', 128)
+sets = bench.make_inputs(layers, 2, torch.device('cuda', 0), 1)
+eng = HeatMapEngine(len(layers), defer_steps=4)
+for t in range(4):
+    for (layer, heads, side, d), (q, k) in zip(layers, sets[t % 2]):
+        eng.tap_qk(layer, q, k, heads, d ** -0.5, factor=64 // side)
+lib = nat.load()
+
+
+def timed(reps=30, **kw):
+    nat.check(lib.daam_profile_enable(eng.ctx, 1))
+    ts = []
+    for r in range(reps + 3):
+        eng.global_heat_map(**kw)
+        ms = ctypes.c_float()
+        nat.check(lib.daam_profile_last_ms(eng.ctx, 1, ctypes.byref(ms)))
+        if r >= 3:
+            ts.append(ms.value * 1e3)
+    nat.check(lib.daam_profile_enable(eng.ctx, 0))
+    return round(float(np.median(ts)), 1), round(float(np.min(ts)), 1)
+
+
+print('finalize us (median, min): all keys', timed(), ' x2 keys only', timed(factors=[2]), ' same-size only', timed(factors=[1]))
+if hasattr(lib, 'daam_debug_dump_pipe'):
+    for name, kw in (('all keys', {}), ('x2 only', dict(factors=[2]))):
+        for r in range(3):
+            eng.global_heat_map(**kw)
+        torch.cuda.synchronize()
+        buf = np.zeros((4096, 6), dtype=np.uint64)
+        print('rc', lib.daam_debug_dump_pipe(buf.ctypes.data_as(ctypes.c_void_p)))
+        b = buf[:2002].astype(np.int64)
+        t0 = b[:, 0].min()
+        b = (b - t0) * 10 / 1000.0   # us
+        print(f'--- {name}: kernel span us: {b[:, 5].max():.1f}')
+        for i, nm in enumerate(['start', 'prefill issued', 'same-size done', 'ops loaded', 'loop done', 'end']):
+            print(f'  {nm:16s} min {b[:, i].min():7.2f} mean {b[:, i].mean():7.2f} max {b[:, i].max():7.2f}')
+        d = np.diff(b, axis=1)
+        print('  phase durations us: mean', np.round(d.mean(0), 2), 'max', np.round(d.max(0), 2))
