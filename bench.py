@@ -22,6 +22,10 @@ all_gather of the final maps, inside the timed region.  ``scaling`` = weak.
 ``python bench.py --gpus N`` outside a launcher re-executes itself under ``torch.distributed.run`` with N ranks (one per
 GPU); it never reports ``n_gpus`` other than the N it was asked for.
 
+The default run also times short legs of the other single-GPU BASELINE configurations (``other_configs``: SD-v1.5 50 steps,
+SDXL 2048 x 2048 100 steps).  ``--gpus N --dist-backend gloo --shared-device`` runs the whole multi-rank path on a one-GPU box.
+Progress goes to stderr; stdout carries the one JSON line.
+
 The one JSON line also carries ``roofline`` (tap kernel: algorithmic bytes / HIP-event time of the launch
 as it occurs in the timed region), ``roofline_issue`` (the same launch against its instruction-issue floor: VALU busy
 cycles from the committed PMC pass of this build + the MFMA issue cost, at the shader clock sampled IN this run while
@@ -586,9 +590,9 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     fin_clock = mon.read()
     fin_bytes = acc_total + 77 * 64 * 64 * 4
     fin_gbs = fin_bytes / (fin_ms * 1e-3) / 1e9
-    fin_kernel = {'sdxl1024': 'table upload + zeroing, finalize_up32_same_kernel (x2 MFMA class and same-size class in one launch)',
+    fin_kernel = {'sdxl1024': 'table upload + zeroing, finalize_up32_pipe_kernel (x2 class software-pipelined on the matrix cores; the same-size keys ride along)',
                   'sdxl2048': 'table upload + zeroing, finalize_down2 (128 -> 64) + finalize_same_kernel',
-                  'sd15': 'table upload + zeroing, finalize_same / finalize_up32_mfma / finalize_up_kernel<16>'}[name]
+                  'sd15': 'table upload + zeroing, finalize_up32_pipe_kernel (x2 + same-size keys) + finalize_up_kernel<16>'}[name]
     fin_issue = dict(bound='issue', kernel=fin_kernel, clock=fin_clock, ms_per_launch=round(fin_ms, 4))
     if rec and fin_clock and rec.get('finalize_valu_busy_cycles_per_simd'):
         n_mfma = rec.get('finalize_mfma_per_simd', 0)

@@ -142,7 +142,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int trips = __builtin_amdgcn_readfirstlane((L.nk_pad - 2) >> 1);              // steady-state loop trips, 2 planes each
     floatx16 accB0, accB1;                                                       // odd planes
     DAAM_PT(3);
-#if DAAM_PIPE_RING == 16
+#if defined(DAAM_PIPE_ABLATE)                                 // timing experiments (tools/gen_fin_pipe.py), results are wrong
+#if DAAM_PIPE_ABLATE == 1
+#include "daam_finalize_pipe_asm_abl1.inc"
+#elif DAAM_PIPE_ABLATE == 2
+#include "daam_finalize_pipe_asm_abl2.inc"
+#elif DAAM_PIPE_ABLATE == 3
+#include "daam_finalize_pipe_asm_abl3.inc"
+#elif DAAM_PIPE_ABLATE == 4
+#include "daam_finalize_pipe_asm_abl4.inc"
+#else
+#include "daam_finalize_pipe_asm_abl5.inc"
+#endif
+#elif DAAM_PIPE_RING == 16
 #include "daam_finalize_pipe_asm_r16.inc"
 #else
 #include "daam_finalize_pipe_asm_r8.inc"

@@ -32,6 +32,13 @@ import sys
 R = int(os.environ.get('DAAM_PIPE_RING', '16'))     # ring slots (planes) per workgroup, 2 KiB each: 8 or 16 (the pointers of the first R planes
                                                      # come in by s_load_dwordx16)
 assert R in (8, 16)
+# timing experiments (results are wrong): 1 no DMA / key loads in the loop, 2 no barrier, 3 no plane reads / vmcnt waits,
+# 4 no VALU (MFMA stream only), 5 no MFMA (VALU stream only)
+ABLATE = int(os.environ.get('DAAM_PIPE_ABLATE', '0'))
+# MFMA / VALU arrangement of a steady iteration: 0 one MFMA per gap (two accumulator chains alternating), 1 the three dependent
+# chains back to back (c0 x4 | c1 x4 | a x2) with the VALU in three blocks behind them, 2 = 1 + s_setprio around the chains,
+# 3 half chains (pairs)
+SCHED = int(os.environ.get('DAAM_PIPE_SCHED', '0'))
 SLOT = 2048
 # ---- register map --------------------------------------------------------------------------------------------------
 WX = (0, 4)               # B operands of pass 1 (4 VGPRs each)
@@ -52,10 +59,13 @@ def mfma(d, a, b, c): return f'v_mfma_f32_32x32x16_f16 {vr(d, 16)}, {vr(a, 4)}, 
 
 def stage_C(pi):
     o, a, b = OSET(pi), ASET(pi), BSET(pi)
-    return [mfma(o, WY[0, 0], b + 0, a), mfma(o + 16, WY[1, 0], b + 0, a + 16),
-            mfma(o, WY[0, 1], b + 4, o), mfma(o + 16, WY[1, 1], b + 4, o + 16),
-            mfma(o, WY[0, 0], b + 8, o), mfma(o + 16, WY[1, 0], b + 8, o + 16),
-            mfma(o, WY[0, 1], b + 12, o), mfma(o + 16, WY[1, 1], b + 12, o + 16)]
+    c0 = [mfma(o, WY[0, 0], b + 0, a), mfma(o, WY[0, 1], b + 4, o), mfma(o, WY[0, 0], b + 8, o), mfma(o, WY[0, 1], b + 12, o)]
+    c1 = [mfma(o + 16, WY[1, 0], b + 0, a + 16), mfma(o + 16, WY[1, 1], b + 4, o + 16), mfma(o + 16, WY[1, 0], b + 8, o + 16),
+          mfma(o + 16, WY[1, 1], b + 12, o + 16)]
+    if SCHED == 0:
+        return [c0[0], c1[0], c0[1], c1[1], c0[2], c1[2], c0[3], c1[3]]
+    return c0 + c1                                     # each accumulator chain back to back (SrcC forwarding)
+
 
 def stage_A():
     return [mfma(T, P[0], WX[0], None), mfma(T, P[1], WX[1], T)]
@@ -83,20 +93,27 @@ def next_key():
 
 def read_plane():
     """after the caller's vmcnt wait: the partner's half has landed once both waves are past the barrier"""
-    return ['s_barrier', f'v_add_u32 v{LDS_TMP}, s{S_RDSLOT}, v{LDS_RD}', f'ds_read_b128 {vr(P[0], 4)}, v{LDS_TMP}',
+    if ABLATE == 3:
+        return []
+    return ([] if ABLATE == 2 else ['s_barrier']) + [f'v_add_u32 v{LDS_TMP}, s{S_RDSLOT}, v{LDS_RD}', f'ds_read_b128 {vr(P[0], 4)}, v{LDS_TMP}',
             f'ds_read_b128 {vr(P[1], 4)}, v{LDS_TMP} offset:32',
             f's_add_u32 s{S_RDSLOT}, s{S_RDSLOT}, {SLOT}', f's_and_b32 s{S_RDSLOT}, s{S_RDSLOT}, {R * SLOT - 1}']
 
-GAPS = [6, 6, 6, 7, 6, 7, 6, 7, 6, 7]       # VALU per MFMA gap (64 per iteration)
+GAPS = {0: [6, 6, 6, 7, 6, 7, 6, 7, 6, 7], 1: [0, 0, 0, 24, 0, 0, 0, 24, 0, 16], 2: [0, 0, 0, 24, 0, 0, 0, 24, 0, 16],
+        3: [0, 12, 0, 12, 0, 12, 0, 12, 0, 16]}[SCHED]       # VALU behind each MFMA (64 per iteration)
 
 def iteration(pi, do_c=True, do_d=True, do_b=True, do_a=True, do_dma=True):
     """one pipeline step for parity pi: C(i) | D(i-1) on set 1-pi | B(i+1) -> set 1-pi | A(i+2)"""
     L = []
     if do_a:
-        L += [f's_waitcnt vmcnt({R - 2})'] + read_plane()
+        L += ([] if ABLATE == 3 else [f's_waitcnt vmcnt({R - 2})']) + read_plane()
     m = (stage_C(pi) if do_c else []) + (stage_A() if do_a else [])
     d = stage_D(1 - pi) if do_d else []
     b = stage_B(1 - pi) if do_b else []
+    if ABLATE == 4 and do_c and do_a:
+        d, b = [], []
+    if ABLATE == 1 and do_c and do_a:
+        do_dma = False
     # VALU order: the first 12 clamps (gaps 0-1: T of the previous A is not readable yet), the split (gaps 2-6, complete
     # before A rewrites T), the remaining clamps
     valu = d[:12] + b + d[12:]
@@ -105,14 +122,24 @@ def iteration(pi, do_c=True, do_d=True, do_b=True, do_a=True, do_dma=True):
         is_a0 = do_a and ins is m[-2]
         if is_a0:
             pass                                    # lgkmcnt(0) was waited in gap 5
-        L.append(ins)
+        steady = do_c and do_a
+        if SCHED == 2 and steady and gi in (0, 4, 8):
+            L.append('s_setprio 1')
+        if not (ABLATE == 5 and steady):
+            L.append(ins)
+        if SCHED == 2 and steady and gi in (3, 7, 9):
+            L.append('s_setprio 0')
         n = GAPS[gi] if (do_c and do_a) else (len(valu) + len(m) - 1) // len(m)
         L += valu[k:k + n]
         k += n
-        if do_dma and do_c and gi == 5:
+        # the plane DMA (behind the lgkmcnt(0) that retires this iteration's plane reads and last iteration's key load) and
+        # the next key load: inside VALU blocks, never between the MFMAs of a chain
+        if do_dma and do_c and gi == (5 if SCHED == 0 else 3):
             L += ['s_waitcnt lgkmcnt(0)'] + dma(S_BASE)
-        if do_dma and do_c and gi == 6:
+        if do_dma and do_c and gi == (6 if SCHED == 0 else 7):
             L += next_key()
+        if SCHED != 0 and ABLATE == 1 and do_c and do_a and gi == 3:
+            L += ['s_waitcnt lgkmcnt(0)']
     L += valu[k:]
     return L
 
@@ -165,7 +192,8 @@ def emit(path, header, lines, outs, ins, clob):
 def main():
     here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'daam_amd', 'csrc')
     pre = build_prefill()
-    emit(os.path.join(here, f'daam_finalize_pipe_prefill_r{R}.inc'),
+    if not ABLATE and not os.environ.get('DAAM_PIPE_OUT'):
+      emit(os.path.join(here, f'daam_finalize_pipe_prefill_r{R}.inc'),
          ['// GENERATED by tools/gen_fin_pipe.py -- do not edit.  Statement 1: LDS-DMA of the first planes of the ring (this wave\'s halves).'],
          pre, '', '"{v208}"(goff), "{s[36:37]}"(key_ptrs), "{s42}"(ring_half)',
          [f'"s{r}"' for r in [S_M0SAVE] + list(range(S_PRE, S_PRE + 2 * R))] + ['"memory"', '"scc"'])
@@ -173,7 +201,7 @@ def main():
     used_v = sorted(set(range(P[0], GOFF)) - set(range(ASET(0), ASET(0) + 64))) + [LDS_TMP]
     clob = [f'"v{r}"' for r in used_v] + [f'"s{r}"' for r in [S_KOFF, 40, 41, S_RDSLOT, S_DMASLOT, 45, S_M0SAVE]]
     clob += ['"memory"', '"scc"', '"vcc"']
-    emit(os.path.join(here, f'daam_finalize_pipe_asm_r{R}.inc'),
+    emit(os.path.join(here, f'daam_finalize_pipe_asm_r{R}.inc' if not (ABLATE or os.environ.get('DAAM_PIPE_OUT')) else (os.environ.get('DAAM_PIPE_OUT') or f'daam_finalize_pipe_asm_abl{ABLATE}.inc')),
          ['// GENERATED by tools/gen_fin_pipe.py -- do not edit; the schedule and its hazard distances are documented there.',
           '// Statement 2: software-pipelined loop over the planes of this workgroup\'s chunk (the ring was started by statement 1), drain.',
           f'// {sum(1 for l in lines if l.startswith("v_mfma"))} MFMA + {sum(1 for l in lines if l.startswith("v_") and not l.startswith("v_mfma"))} VALU statements in the text; ring of {R} planes per workgroup.'],

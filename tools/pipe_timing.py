@@ -29,17 +29,23 @@ def timed(reps=30, **kw):
     return round(float(np.median(ts)), 1), round(float(np.min(ts)), 1)
 
 
-print('finalize us (median, min): all keys', timed(), ' x2 keys only', timed(factors=[2]), ' same-size only', timed(factors=[1]))
+BRIEF = bool(os.environ.get('PIPE_TIMING_BRIEF'))
+if not BRIEF:
+    print('finalize us (median, min): all keys', timed(), ' x2 keys only', timed(factors=[2]), ' same-size only', timed(factors=[1]))
 if hasattr(lib, 'daam_debug_dump_pipe'):
     for name, kw in (('all keys', {}), ('x2 only', dict(factors=[2]))):
         for r in range(3):
             eng.global_heat_map(**kw)
         torch.cuda.synchronize()
         buf = np.zeros((4096, 6), dtype=np.uint64)
-        print('rc', lib.daam_debug_dump_pipe(buf.ctypes.data_as(ctypes.c_void_p)))
+        rc = lib.daam_debug_dump_pipe(buf.ctypes.data_as(ctypes.c_void_p))
         b = buf[:2002].astype(np.int64)
         t0 = b[:, 0].min()
         b = (b - t0) * 10 / 1000.0   # us
+        d = np.diff(b, axis=1)
+        if BRIEF:
+            print(f'{os.environ.get("DAAM_HIP_LIB", "default")[-12:]} {name}: span {b[:, 5].max():.1f} us; loop mean {d[:, 3].mean():.1f} min {d[:, 3].min():.1f} max {d[:, 3].max():.1f}; same-size phase mean {d[:, 1].mean():.1f}')
+            continue
         print(f'--- {name}: kernel span us: {b[:, 5].max():.1f}')
         for i, nm in enumerate(['start', 'prefill issued', 'same-size done', 'ops loaded', 'loop done', 'end']):
             print(f'  {nm:16s} min {b[:, i].min():7.2f} mean {b[:, i].mean():7.2f} max {b[:, i].max():7.2f}')
