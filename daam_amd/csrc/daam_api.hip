@@ -859,9 +859,11 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         else forked = true;
     }
     std::vector<size_t> launch_order;                        // side kinds first, the main one last
+    static const bool main_first = getenv("DAAM_TAP_MAIN_FIRST") && getenv("DAAM_TAP_MAIN_FIRST")[0] == '1';   // A/B switch
+    if (forked && main_first) launch_order.push_back(main_idx);
     for (size_t i = 0; i < prepared.size(); ++i)
         if (!forked || i != main_idx) launch_order.push_back(i);
-    if (forked) launch_order.push_back(main_idx);
+    if (forked && !main_first) launch_order.push_back(main_idx);
     int n_side = 0;
     for (size_t pi : launch_order) {
         if (rc) break;

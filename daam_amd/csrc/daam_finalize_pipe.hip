@@ -69,7 +69,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)(&ring[0]));
     const unsigned ring_half = ring_base + (unsigned)nt * 1024u;
     const unsigned lds_rd = ring_base + (unsigned)n * 64u + (unsigned)g * 16u;    // A piece: row n, columns 8g.. (+32 bytes: 16 + 8g..)
-#if DAAM_PIPE_RING == 16
+#if defined(DAAM_PIPE_ABLATE)
+#include "daam_finalize_pipe_prefill_ablx.inc"
+#elif DAAM_PIPE_RING == 16
 #include "daam_finalize_pipe_prefill_r16.inc"
 #else
 #include "daam_finalize_pipe_prefill_r8.inc"

@@ -25,6 +25,11 @@
 // (TCP_TOTAL_CACHE_ACCESSES, TCP_READ_TAGCONFLICT_STALL_CYCLES; profiles/r02_tap_tcp.txt).
 #include "daam_tap16_softmax.h"
 
+// cache policy of the Q fetches (every Q row is read exactly once per launch): 0 = default, 2 = non-temporal (A/B: -DDAAM_TAP_Q_AUX=2)
+#ifndef DAAM_TAP_Q_AUX
+#define DAAM_TAP_Q_AUX 0
+#endif
+
 namespace daam {
 
 constexpr int kTapRow = 128;                        // bytes per K / Q row in LDS (head_dim 64 x fp16), chunks swizzled
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     auto issue_q = [&](int s) {
         const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) qreg[i] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(qt, q_b0, q_s[i], 0));
+        for (int i = 0; i < 4; ++i) qreg[i] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(qt, q_b0, q_s[i], DAAM_TAP_Q_AUX));
     };
     auto commit_q = [&]() {
 #pragma unroll

@@ -39,6 +39,7 @@ ABLATE = int(os.environ.get('DAAM_PIPE_ABLATE', '0'))
 # chains back to back (c0 x4 | c1 x4 | a x2) with the VALU in three blocks behind them, 2 = 1 + s_setprio around the chains,
 # 3 half chains (pairs)
 SCHED = int(os.environ.get('DAAM_PIPE_SCHED', '0'))
+NT = ' nt' if os.environ.get('DAAM_PIPE_NT') else ''     # cache policy of the plane fetches (every plane is read once)
 SLOT = 2048
 # ---- register map --------------------------------------------------------------------------------------------------
 WX = (0, 4)               # B operands of pass 1 (4 VGPRs each)
@@ -85,7 +86,7 @@ def stage_B(s):
 
 def dma(base):
     """this wave's half of a plane -> ring slot S_DMASLOT (S_RING already points at the wave's half of slot 0), advance the slot"""
-    return [f's_add_u32 m0, s{S_RING}, s{S_DMASLOT}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF}, s[{base}]',
+    return [f's_add_u32 m0, s{S_RING}, s{S_DMASLOT}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF}, s[{base}]{NT}',
             f's_add_u32 s{S_DMASLOT}, s{S_DMASLOT}, {SLOT}', f's_and_b32 s{S_DMASLOT}, s{S_DMASLOT}, {R * SLOT - 1}']
 
 def next_key():
@@ -150,7 +151,7 @@ def build_prefill():
         L += [f's_load_dwordx16 s[{S_PRE + 16}:{S_PRE + 31}], s[{S_KEYS}], 0x40']
     L += ['s_waitcnt lgkmcnt(0)']
     for q in range(R):
-        L += [f's_add_u32 m0, s{S_RING}, 0x{q * SLOT:x}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF}, s[{S_PRE + 2 * q}:{S_PRE + 2 * q + 1}]']
+        L += [f's_add_u32 m0, s{S_RING}, 0x{q * SLOT:x}', 's_nop 0', f'global_load_lds_dwordx4 v{GOFF}, s[{S_PRE + 2 * q}:{S_PRE + 2 * q + 1}]{NT}']
     L += [f's_mov_b32 m0, s{S_M0SAVE}']
     return L
 
@@ -192,8 +193,8 @@ def emit(path, header, lines, outs, ins, clob):
 def main():
     here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'daam_amd', 'csrc')
     pre = build_prefill()
-    if not ABLATE and not os.environ.get('DAAM_PIPE_OUT'):
-      emit(os.path.join(here, f'daam_finalize_pipe_prefill_r{R}.inc'),
+    if not ABLATE:
+      emit(os.path.join(here, f'daam_finalize_pipe_prefill_r{R}.inc' if not os.environ.get('DAAM_PIPE_OUT') else 'daam_finalize_pipe_prefill_ablx.inc'),
          ['// GENERATED by tools/gen_fin_pipe.py -- do not edit.  Statement 1: LDS-DMA of the first planes of the ring (this wave\'s halves).'],
          pre, '', '"{v208}"(goff), "{s[36:37]}"(key_ptrs), "{s42}"(ring_half)',
          [f'"s{r}"' for r in [S_M0SAVE] + list(range(S_PRE, S_PRE + 2 * R))] + ['"memory"', '"scc"'])
