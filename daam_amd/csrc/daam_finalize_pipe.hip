@@ -99,8 +99,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 8; ++e) sel[ks][e] = (_Float16)((n == 16 * ks + 8 * g + e) ? 1.0f : 0.0f);
         const unsigned long long* sp = L.same_ptrs + (size_t)chunk * L.same_per;
         const unsigned soff = (unsigned)tok * (64u * 64u * 2u) + (unsigned)n * 128u + (unsigned)(32 * nt + 8 * g) * 2u;
-        // the pieces of kSameBatch keys are fetched together (the kernel is bound by memory latency: one round trip per batch,
-        // not per key); padding entries are null (wave-uniform) and re-read the first key's pieces, unused
+        // the pieces of kSameBatch keys are fetched together (one memory round trip per batch, not per key); padding entries are
+        // null (wave-uniform)
         for (int j0 = 0; j0 < L.same_per; j0 += kSameBatch) {
             half8 a[kSameBatch][2][2];
             unsigned long long ptr[kSameBatch];
@@ -108,13 +108,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int j = 0; j < kSameBatch; ++j) ptr[j] = j0 + j < L.same_per ? sp[j0 + j] : 0ull;
 #pragma unroll
             for (int j = 0; j < kSameBatch; ++j) {
+                // a padding slot re-reads the batch's first key (its result is not used); a chunk without any same-size key
+                // (fewer keys than chunks) has ptr[0] == 0 and fetches nothing: no address is formed from a null pointer
                 const char* base = reinterpret_cast<const char*>(ptr[j] ? ptr[j] : ptr[0]);
-                if (!base) base = reinterpret_cast<const char*>(L.mfma_ops);     // an empty batch cannot happen; stay in bounds anyway
+                if (base) {                                                      // wave-uniform
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-                        a[j][mt][ks] = *as_global<half8>(base + soff + mt * (32 * 128) + ks * 32);
+                        for (int ks = 0; ks < 2; ++ks)
+                            a[j][mt][ks] = *as_global<half8>(base + soff + mt * (32 * 128) + ks * 32);
+                }
             }
 #pragma unroll
             for (int j = 0; j < kSameBatch; ++j) {

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void mask_overlap_kernel(const float* a, int a
                 rows[t] = r[ix[0]] * wx[0] + r[ix[1]] * wx[1] + r[ix[2]] * wx[2] + r[ix[3]] * wx[3];
             }
             const float v = rows[0] * wy[0] + rows[1] * wy[1] + rows[2] * wy[2] + rows[3] * wy[3];
-            va = v < 1.0f ? 0.0f : 1.0f;                       // a[a < 1] = 0; a[a >= 1] = 1  (evaluate.py:17-18)
+            va = v < 1.0f ? 0.0f : (v >= 1.0f ? 1.0f : v);    // a[a < 1] = 0; a[a >= 1] = 1  (evaluate.py:17-18): a NaN stays a NaN
         }
     }
     float inter = va * vb, sa = va, sb = vb;

@@ -140,7 +140,7 @@ DAAM_API int daam_tap_probs(DaamCtx* ctx, int layer, const void* probs, int in_d
  * has to stay alive after the call.  `tap` = 0 leaves the layer's sums alone (the caller records q, k for a deferred
  * daam_tap_qk_enqueue, or the call is not tapped: reference gate daam/trace.py:289).
  * v is [batch, tokens, heads * head_dim] like k; out is written as [batch, hw, heads * head_dim] in the given strides
- * (ELEMENTS; head_dim contiguous).  Supported: DAAM_F16, head_dim a multiple of 8 up to 160 (SDXL / SD-2.x 64, SD-v1.5 40 /
+ * (ELEMENTS; head_dim contiguous).  Supported: DAAM_F16 and DAAM_BF16 (bf16: round_logits = 1 only), head_dim a multiple of 8 up to 160 (SDXL / SD-2.x 64, SD-v1.5 40 /
  * 80 / 160), tokens 77, hw and strides multiples of 8, 16-byte aligned pointers -- daam_attend_supported() tells; otherwise DAAM_E_UNSUPPORTED and the
  * caller uses its framework's attention plus daam_tap_qk. */
 typedef struct DaamAttendDesc {

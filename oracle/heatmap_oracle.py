@@ -314,7 +314,8 @@ def _resize_binarise(a: np.ndarray, b_shape) -> np.ndarray:
     out = np.zeros((oh, ow), dtype=np.float32)
     for t in range(4):
         out += rows[iy[:, t], :] * wy[:, t][:, None]
-    return np.where(out < 1, np.float32(0), np.float32(1)).astype(np.float32)
+    # two masked assignments in the reference: a NaN satisfies neither and stays a NaN
+    return np.where(out < 1, np.float32(0), np.where(out >= 1, np.float32(1), out)).astype(np.float32)
 
 
 def mask_overlap(a: np.ndarray, b: np.ndarray):

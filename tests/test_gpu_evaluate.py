@@ -74,3 +74,16 @@ def test_word_heat_map_compute_ioa_and_errors():
     assert abs(daam_amd.compute_iou(a_cpu, b_cpu) - ho.compute_iou(x, (y > 0.5).astype(np.float32))) <= 1e-6
     with pytest.raises(daam_amd._native.DaamError):
         daam_amd.compute_iou(torch.zeros(8, 4, device=DEV), torch.zeros(8, 6, device=DEV))   # same height, other width
+
+
+def test_nan_prediction_gives_nan_like_the_reference():
+    """evaluate.py:17-18 are two masked assignments: a NaN in the resized prediction satisfies neither, stays a NaN and makes
+    the ratio NaN (round-2 advisor: the kernel used to turn it into 1)."""
+    import daam_amd
+    a = torch.ones(8, 8)
+    a[3, 4] = float('nan')
+    b = (torch.rand(32, 32, generator=torch.Generator().manual_seed(1)) > 0.5).float()
+    assert np.isnan(daam_amd.compute_iou(a.to(DEV), b.to(DEV))) and np.isnan(daam_amd.compute_ioa(a.to(DEV), b.to(DEV)))
+    assert np.isnan(ho.compute_iou(a.numpy(), b.numpy()))
+    a[3, 4] = 1.0
+    assert abs(daam_amd.compute_iou(a.to(DEV), b.to(DEV)) - ho.compute_iou(a.numpy(), b.numpy())) <= 1e-6
