@@ -26,11 +26,17 @@ namespace daam {
 
 // debug aid (tools/pipe_timing.py; build with -DDAAM_PIPE_TIMING): per-wave phase timestamps (100 MHz reference counter)
 #ifdef DAAM_PIPE_TIMING
-__device__ unsigned long long daam_pipe_dbg[4096][6];
+__device__ unsigned long long daam_pipe_dbg[4096][8];     // [0..5] phase stamps (100 MHz), [6..7] shader-cycle counter around the loop
 #define DAAM_PT(i) do { if ((threadIdx.x & 63) == 0) { const unsigned w_ = (blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 6); \
     if (w_ < 4096) daam_pipe_dbg[w_][i] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define DAAM_PT(i) do {} while (0)
+#endif
+#ifdef DAAM_PIPE_TIMING
+#define DAAM_PC(i) do { if ((threadIdx.x & 63) == 0) { const unsigned w_ = (blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 6); \
+    if (w_ < 4096) daam_pipe_dbg[w_][i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define DAAM_PC(i) do {} while (0)
 #endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int trips = __builtin_amdgcn_readfirstlane((L.nk_pad - 2) >> 1);              // steady-state loop trips, 2 planes each
     floatx16 accB0, accB1;                                                       // odd planes
     DAAM_PT(3);
+    DAAM_PC(6);
 #if defined(DAAM_PIPE_ABLATE)                                 // timing experiments (tools/gen_fin_pipe.py), results are wrong
 #if DAAM_PIPE_ABLATE == 1
 #include "daam_finalize_pipe_asm_abl1.inc"
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #include "daam_finalize_pipe_asm_r8.inc"
 #endif
 
+    DAAM_PC(7);
     DAAM_PT(4);
     if (!same_first) same_size_keys();
     // C/D layout: lane (n, g) owns out[32 mt + 8 b + 4 g + r][32 nt + n] in register 4 b + r of tile mt

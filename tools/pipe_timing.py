@@ -14,6 +14,17 @@ for t in range(4):
     for (layer, heads, side, d), (q, k) in zip(layers, sets[t % 2]):
         eng.tap_qk(layer, q, k, heads, d ** -0.5, factor=64 // side)
 lib = nat.load()
+HOT = bool(os.environ.get('PIPE_TIMING_HOT'))     # measure right behind back-to-back 50-step tap launches (the power-limited state of bench.py)
+if HOT:
+    hot_sets = bench.make_inputs(layers, 50, torch.device('cuda', 0), 2)
+    hot_calls = bench.call_lists(layers, hot_sets, 64)
+
+
+def heat():
+    if HOT:
+        for _ in range(12):
+            bench.one_generation(eng, hot_calls, 50)
+
 
 
 def timed(reps=30, **kw):
@@ -34,15 +45,20 @@ if not BRIEF:
     print('finalize us (median, min): all keys', timed(), ' x2 keys only', timed(factors=[2]), ' same-size only', timed(factors=[1]))
 if hasattr(lib, 'daam_debug_dump_pipe'):
     for name, kw in (('all keys', {}), ('x2 only', dict(factors=[2]))):
+        heat()
         for r in range(3):
             eng.global_heat_map(**kw)
         torch.cuda.synchronize()
-        buf = np.zeros((4096, 6), dtype=np.uint64)
+        buf = np.zeros((4096, 8), dtype=np.uint64)
         rc = lib.daam_debug_dump_pipe(buf.ctypes.data_as(ctypes.c_void_p))
-        b = buf[:2002].astype(np.int64)
+        cyc = (buf[:2002, 7].astype(np.int64) - buf[:2002, 6].astype(np.int64)).astype(np.float64)
+        b = buf[:2002, :6].astype(np.int64)
         t0 = b[:, 0].min()
         b = (b - t0) * 10 / 1000.0   # us
         d = np.diff(b, axis=1)
+        mhz = cyc / np.maximum(d[:, 3], 1e-3)                     # shader cycles per us of the loop = MHz while it ran
+        print(f'  shader clock during the loop: median {np.median(mhz):.0f} MHz (min {mhz.min():.0f}, max {mhz.max():.0f}); '
+              f'loop cycles per wave-iteration: median {np.median(cyc) / 78:.0f}')
         if BRIEF:
             print(f'{os.environ.get("DAAM_HIP_LIB", "default")[-12:]} {name}: span {b[:, 5].max():.1f} us; loop mean {d[:, 3].mean():.1f} min {d[:, 3].min():.1f} max {d[:, 3].max():.1f}; same-size phase mean {d[:, 1].mean():.1f}')
             continue
