@@ -679,3 +679,18 @@ def test_generation_experiment_round_trip(tmp_path):
     assert back.heat_map().prompt == 'a dog'
     back.clear_checkpoint()
     assert not (root / 'base' / 'generation.pt').exists()
+
+
+def test_generated_finalize_schedule_is_current(tmp_path):
+    """daam_amd/csrc/daam_finalize_pipe_{prefill,asm}_r{8,16}.inc are generated (tools/gen_fin_pipe.py): the committed files must
+    be what the generator writes today, for both ring depths."""
+    import subprocess
+    import sys
+    for ring in ('8', '16'):
+        env = dict(os.environ, DAAM_PIPE_RING=ring, DAAM_PIPE_OUTDIR=str(tmp_path))
+        for k in ('DAAM_PIPE_ABLATE', 'DAAM_PIPE_SCHED', 'DAAM_PIPE_NT', 'DAAM_PIPE_OUT'):
+            env.pop(k, None)
+        subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen_fin_pipe.py')], env=env, check=True, capture_output=True)
+        for kind in ('prefill', 'asm'):
+            name = f'daam_finalize_pipe_{kind}_r{ring}.inc'
+            assert open(os.path.join(str(tmp_path), name)).read() == open(os.path.join(ROOT, 'daam_amd', 'csrc', name)).read(), name

@@ -191,7 +191,7 @@ def emit(path, header, lines, outs, ins, clob):
 
 
 def main():
-    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'daam_amd', 'csrc')
+    here = os.environ.get('DAAM_PIPE_OUTDIR') or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'daam_amd', 'csrc')
     pre = build_prefill()
     if not ABLATE:
       emit(os.path.join(here, f'daam_finalize_pipe_prefill_r{R}.inc' if not os.environ.get('DAAM_PIPE_OUT') else 'daam_finalize_pipe_prefill_ablx.inc'),
