@@ -5,8 +5,8 @@ R=$(pwd); O=${1:-gpurun_out/power}; mkdir -p $O
 sample() { rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | sed -E 's/^GPU\[0\][[:space:]]*:[[:space:]]*//' | tr '\n' ';'; echo; }
 echo "# idle" > $O/power_sclk.txt
 for i in 1 2 3; do echo "$(date +%s.%N) $(sample)" >> $O/power_sclk.txt; sleep 0.3; done
-echo "# under python bench.py --no-baselines --no-integrated --steps 5000 --warmup 10 (tap launches back to back)" >> $O/power_sclk.txt
-python bench.py --no-baselines --no-integrated --steps 5000 --warmup 10 > $O/bench_power.json 2> $O/bench_power.err &
+echo "# under python bench.py --no-baselines --no-integrated --no-other-configs --steps 5000 --warmup 10 (tap launches back to back)" >> $O/power_sclk.txt
+python bench.py --no-baselines --no-integrated --no-other-configs --steps 5000 --warmup 10 > $O/bench_power.json 2> $O/bench_power.err &
 BP=$!
 while kill -0 $BP 2>/dev/null; do echo "$(date +%s.%N) $(sample)" >> $O/power_sclk.txt; sleep 0.3; done
 echo "# idle again" >> $O/power_sclk.txt
