@@ -17,8 +17,9 @@
 // k split).  C/D: lane holds pixel l&15 and tokens 16*mt + 4*(l>>4) + r (mt = 0..4, r = 0..3) = 20 slots.
 // Both operands reach the MFMAs through LDS in FULL 128-byte rows: K of a step as [80 rows][128 B],
 // double-buffered; Q of a step as a wave-private [32 pixel rows][128 B] tile.  Either is fetched from
-// HBM one step ahead into registers by coalesced loads (eight consecutive lanes = one whole row) and
-// written with its 16-byte chunks XOR-swizzled by (row >> 1) & 7, which makes the operand reads
+// HBM one step ahead by coalesced loads (eight consecutive lanes = one whole row) -- straight into LDS by LDS-DMA for
+// head_dim 64 (round 3), through staging registers otherwise -- with its 16-byte chunks XOR-swizzled by (row >> 1) & 7,
+// which makes the operand reads
 // (16 rows x one chunk per ds_read_b128) conflict-free without padding.  Round 2 fetched Q straight into
 // the MFMA layout (16 rows x 64 B per load instruction): the same bytes, but 16 bytes per L1 tag
 // lookup -- 0.67 lookups per cycle per CU and a read-tag-conflict stall in 20 % of the cycles
@@ -28,6 +29,15 @@
 // cache policy of the Q fetches (every Q row is read exactly once per launch): 0 = default, 2 = non-temporal (A/B: -DDAAM_TAP_Q_AUX=2)
 #ifndef DAAM_TAP_Q_AUX
 #define DAAM_TAP_Q_AUX 0
+#endif
+// K and Q of head_dim-64 launches (FULL64: every SDXL / SD-2.x layer) go HBM -> LDS by LDS-DMA (buffer_load ... lds: the swizzle is
+// applied to the SOURCE address, the LDS image of a wave-instruction is lane-linear) instead of through staging registers +
+// ds_write_b128: seven ds_write_b128 and 24 VGPRs fewer per lane-step (122 -> 98).  Round 3, on the full-row data path: +0.7 ... +2.4 %
+// heat maps / s depending on the box (round 1 measured the DMA form 10 % SLOWER on the fragment-shaped path).  One K buffer + a second
+// barrier (27 KB of LDS, 5 waves per SIMD) measured the same as two.  -DDAAM_TAP_DMA=0 brings the register-staged form back for A/B
+// runs; head_dim < 64 (zero-padded chunks cannot come from a DMA) always takes it.
+#ifndef DAAM_TAP_DMA
+#define DAAM_TAP_DMA 1
 #endif
 
 namespace daam {
@@ -90,7 +100,11 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     const int64_t k_off = b * lay.k_sb + hd * lay.k_sh;
     const int64_t q_off = b * lay.q_sb + hd * lay.q_sh;
 
+#if DAAM_TAP_DMA
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the DMA block choice must not become exec masks
+#else
     const int lane = tid & 63, wave = tid >> 6;
+#endif
     const int j = lane & 15, h = lane >> 4;
 
     // ---- running sums -> registers (through the staging tile, 16-byte row pieces) --------------
@@ -211,6 +225,42 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         }
     };
 
+#if DAAM_TAP_DMA
+    // LDS-DMA form (FULL64 launches only).  K: 1 KiB block blk = 4 j2 + wave (10 blocks: rows 8 blk .. 8 blk + 7; rows 77..79 re-read
+    // row 76: finite, their logits are masked); lane -> row 8 blk + (lane >> 3), LDS chunk slot lane & 7 = source chunk
+    // (lane & 7) ^ ((row >> 1) & 7).  Q: block i = rows 8 i .. 8 i + 7 of the wave's 32, same rule.
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    unsigned kd_src[3];
+#pragma unroll
+    for (int j2 = 0; j2 < 3; ++j2) {
+        const int blk = 4 * j2 + wave;
+        const int row = min(8 * blk + (lane >> 3), kTok - 1);
+        const int ch = (lane & 7) ^ (((8 * blk + (lane >> 3)) >> 1) & 7);
+        kd_src[j2] = (unsigned)((row * (int)lay.k_st + ch * 8) * 2);
+    }
+    unsigned qd_src[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int ch = (lane & 7) ^ ((4 * par + (lane >> 4)) & 7);
+        const int px = p0 + wave * 32 + (lane >> 3);
+        qd_src[par] = (unsigned)((q_off + (int64_t)min(px, lay.hw - 1) * lay.q_sp) * 2) + (unsigned)ch * 16u;
+    }
+    auto dma_k = [&](int s, int buf) {
+        const __amdgpu_buffer_rsrc_t kt = tensor(sptr[2 * s + 1]);
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2) {
+            const int blk = 4 * j2 + wave;                    // wave-uniform
+            if (blk < 10)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(kt, (lds_ptr_t)(kbuf + buf * kTapKBuf + blk * 1024), 16, kd_src[j2], k_base, 0, 0);
+        }
+    };
+    auto dma_q = [&](int s) {
+        const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(qtile + i * 1024), 16, qd_src[i & 1], q_s[i], 0, DAAM_TAP_Q_AUX);
+    };
+#endif
     // one denoising step: logits of step s from the K and Q tiles in LDS, then the fetches of step s + 1 into registers,
     // softmax + accumulate of the two pixel groups, K and Q of step s + 1 into LDS (K: the other buffer; Q: this wave's
     // own tile, whose reads are behind it)
@@ -232,7 +282,17 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             c0[mt] = IN::mfma(a1, q01, c0[mt]);
             c1[mt] = IN::mfma(a1, q11, c1[mt]);
         }
-#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 2           // timing experiment 2: every step re-reads step 0 (cache-resident)
+#if DAAM_TAP_DMA
+        if constexpr (FULL64) {
+            // the K buffer of step s + 1 was last read in step s - 1 (every wave is past this step's barrier); this wave's Q
+            // tile was read by the operand loads above, which the MFMAs have consumed
+            dma_k(min(s + 1, n_steps - 1), (s + 1) & 1);
+            dma_q(min(s + 1, n_steps - 1));
+        } else {
+            issue_k(min(s + 1, n_steps - 1));
+            issue_q(min(s + 1, n_steps - 1));
+        }
+#elif defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 2           // timing experiment 2: every step re-reads step 0 (cache-resident)
         issue_k(0);
         issue_q(0);
 #else
@@ -246,13 +306,35 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             softmax20_accumulate<ACC_T, FAST_EXP>(c0, lay, h, run0);
             softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
         }
+#if DAAM_TAP_DMA
+        if constexpr (FULL64) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs have landed; the next step's barrier publishes K
+        } else {
+            commit_k((s + 1) & 1);
+            commit_q();
+        }
+#else
         commit_k((s + 1) & 1);
         commit_q();
+#endif
     };
+#if DAAM_TAP_DMA
+    if constexpr (FULL64) {
+        dma_k(0, 0);
+        dma_q(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        issue_k(0);
+        issue_q(0);
+        commit_k(0);
+        commit_q();
+    }
+#else
     issue_k(0);
     issue_q(0);
     commit_k(0);
     commit_q();
+#endif
     for (int s = 0; s < n_steps; ++s) step(s);
     __syncthreads();                                          // all K reads done before the staging tile reuses the space
 
