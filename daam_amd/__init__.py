@@ -5,7 +5,7 @@ from .hook import *          # noqa: F401,F403
 from .utils import *         # noqa: F401,F403
 from .heatmap import *       # noqa: F401,F403
 from .trace import *         # noqa: F401,F403
-from .experiment import GenerationExperiment  # noqa: F401
-from .evaluate import compute_iou, compute_ioa  # noqa: F401
+from .experiment import *    # noqa: F401,F403
+from .evaluate import compute_iou, compute_ioa, load_mask, MeanEvaluator, UnsupervisedEvaluator  # noqa: F401
 
 __version__ = '0.1.0'

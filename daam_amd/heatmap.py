@@ -3,15 +3,16 @@ per-(factor, layer, head) collection -- here a zero-copy view over the device ru
 and ``GlobalHeatMap`` / ``WordHeatMap``, whose arithmetic runs in ``libdaam_hip.so``."""
 from __future__ import annotations
 
+from dataclasses import dataclass
 from functools import lru_cache
-from typing import Any, Iterator, Optional, Set, Tuple
+from typing import Any, Iterable, Iterator, Optional, Set, Tuple
 
 import torch
 
 from . import engine as _engine
-from .utils import compute_token_merge_indices
+from .utils import cached_nlp, compute_token_merge_indices
 
-__all__ = ['GlobalHeatMap', 'RawHeatMapCollection', 'WordHeatMap']
+__all__ = ['GlobalHeatMap', 'RawHeatMapCollection', 'WordHeatMap', 'ParsedHeatMap', 'SyntacticHeatMapPair']
 
 RawHeatMapKey = Tuple[int, int, int]  # factor, layer, head
 
@@ -81,9 +82,25 @@ class WordHeatMap:
                               color_normalize=color_normalize, ax=ax)
 
 
+@dataclass
+class SyntacticHeatMapPair:
+    """A dependency arc of the prompt with the word maps at both ends (heatmap.py:99-105)."""
+    head_heat_map: WordHeatMap
+    dep_heat_map: WordHeatMap
+    head_text: str
+    dep_text: str
+    relation: str
+
+
+@dataclass
+class ParsedHeatMap:
+    """A parsed prompt token with its word map (heatmap.py:108-111); ``token`` is the parser's token object."""
+    word_heat_map: WordHeatMap
+    token: Any
+
+
 class GlobalHeatMap:
-    """reference heatmap.py:114-142 (the spaCy-based ``parsed_heat_maps`` /
-    ``dependency_relations`` helpers are outside the hot-path scope)."""
+    """reference heatmap.py:114-142."""
 
     def __init__(self, tokenizer: Any, prompt: str, heat_maps: torch.Tensor):
         self.tokenizer = tokenizer
@@ -94,3 +111,24 @@ class GlobalHeatMap:
     def compute_word_heat_map(self, word: str, word_idx: Optional[int] = None, offset_idx: int = 0) -> WordHeatMap:
         merge_idxs, word_idx = compute_token_merge_indices(self.tokenizer, self.prompt, word, word_idx, offset_idx)
         return WordHeatMap(_engine.word_heat_map(self.heat_maps, merge_idxs), word, word_idx)
+
+    def parsed_heat_maps(self) -> Iterable[ParsedHeatMap]:
+        """One ``ParsedHeatMap`` per token of the parsed prompt whose text is found among the prompt's tokenizer tokens
+        (heatmap.py:125-131; the others are skipped)."""
+        for token in cached_nlp(self.prompt):
+            try:
+                yield ParsedHeatMap(self.compute_word_heat_map(token.text), token)
+            except ValueError:
+                continue
+
+    def dependency_relations(self) -> Iterable[SyntacticHeatMapPair]:
+        """One pair per non-root token: the maps of the token and of its syntactic head (heatmap.py:133-142)."""
+        for token in cached_nlp(self.prompt):
+            if token.dep_ == 'ROOT':
+                continue
+            try:
+                dependent = self.compute_word_heat_map(token.text)
+                head = self.compute_word_heat_map(token.head.text)
+            except ValueError:
+                continue
+            yield SyntacticHeatMapPair(head, dependent, token.head.text, token.text, token.dep_)

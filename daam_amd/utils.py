@@ -1,19 +1,21 @@
 """Host helpers next to the extraction path, with the names and behaviour of the reference's
 ``daam/utils.py`` (device / autocast policy :22-36, seeding :46-55, cache directory :58-70, prompt-word to
-heat-map-row mapping :73-91).  spaCy and matplotlib are not needed here (the reference's ``cached_nlp`` /
-``plot_mask_heat_map`` belong to its CLI / plotting layer)."""
+heat-map-row mapping :73-91, the cached spaCy parse :94-109, the thresholded-mask plot :39-43).  spaCy and matplotlib are
+imported only by the two helpers that need them."""
 from __future__ import annotations
 
 import os
 import random
 import sys
 from pathlib import Path
-from typing import List, Optional, Sequence, Tuple
+from functools import lru_cache
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
-__all__ = ['set_seed', 'compute_token_merge_indices', 'cache_dir', 'auto_device', 'auto_autocast']
+__all__ = ['set_seed', 'compute_token_merge_indices', 'plot_mask_heat_map', 'cached_nlp', 'set_nlp', 'cache_dir',
+           'auto_device', 'auto_autocast']
 
 _EOW = '</w>'        # CLIP BPE end-of-word marker
 
@@ -88,3 +90,44 @@ def compute_token_merge_indices(tokenizer, prompt: str, word: str, word_idx: Opt
     if not rows:
         raise ValueError(f'Search word {word} not found in prompt!')
     return rows, word_idx
+
+
+def plot_mask_heat_map(im, heat_map: torch.Tensor, threshold: float = 0.4):
+    """Show the image with everything outside ``heat_map > threshold`` blacked out (utils.py:39-43)."""
+    from matplotlib import pyplot as plt
+    keep = (heat_map.detach().squeeze().to('cpu', torch.float32) > threshold).to(torch.float32)
+    pixels = torch.from_numpy(np.array(im)).to(torch.float32) / 255
+    plt.imshow(pixels * keep.unsqueeze(-1))
+
+
+_parsers: dict = {}        # spaCy pipeline name -> loaded pipeline (or whatever ``set_nlp`` registered)
+
+
+def set_nlp(parser: Optional[Callable], type: str = 'en_core_web_md') -> None:
+    """Register the callable ``prompt -> parsed document`` that ``cached_nlp`` uses for pipeline ``type`` (``None`` forgets
+    it): a spaCy pipeline loaded elsewhere, or any parser whose tokens carry ``.text`` / ``.dep_`` / ``.head``."""
+    if parser is None:
+        _parsers.pop(type, None)
+    else:
+        _parsers[type] = parser
+    cached_nlp.cache_clear()
+
+
+@lru_cache(maxsize=100000)
+def cached_nlp(prompt: str, type: str = 'en_core_web_md'):
+    """The spaCy parse of ``prompt``, cached per (prompt, pipeline) like the reference's (utils.py:97-109).  The pipeline is
+    loaded on first use; a missing model is an error that names it (the reference shells out to ``spacy download`` --
+    nothing is downloaded here)."""
+    parser = _parsers.get(type)
+    if parser is None:
+        try:
+            import spacy
+        except ImportError as exc:
+            raise ImportError('daam_amd: parsed_heat_maps / dependency_relations need spaCy (or a parser registered with '
+                              'daam_amd.utils.set_nlp)') from exc
+        try:
+            parser = spacy.load(type)
+        except OSError as exc:
+            raise OSError(f'daam_amd: spaCy pipeline {type!r} is not installed (python -m spacy download {type})') from exc
+        _parsers[type] = parser
+    return parser(prompt)

@@ -257,15 +257,157 @@ def run_evaluate(daam):
     print(f'evaluate: {len(evaluate_inputs())} groups, {os.path.getsize(path) / 1e6:.2f} MB')
 
 
+EXPERIMENT_DIR = os.path.join(OUT_DIR, 'experiment_ref')
+
+PARSED_PROMPT = 'a fluffy cat chases the elephant'
+# a stand-in dependency parse of PARSED_PROMPT: (text, relation, index of the head token).  'quickly' and '.' are tokens the
+# parser reports that the tokenizer's tokens of the prompt do not contain (skipped by the reference, heatmap.py:130,141).
+PARSED_TOKENS = [('a', 'det', 2), ('fluffy', 'amod', 2), ('cat', 'nsubj', 3), ('chases', 'ROOT', 3), ('the', 'det', 5),
+                 ('elephant', 'dobj', 3), ('quickly', 'advmod', 3), ('.', 'punct', 6)]
+
+
+class ParsedToken:
+    def __init__(self, text, dep):
+        self.text, self.dep_, self.head = text, dep, None
+
+
+def fake_parse(prompt):
+    """What a spaCy pipeline would return, as far as the reference looks at it: tokens with ``.text`` / ``.dep_`` / ``.head``."""
+    assert prompt == PARSED_PROMPT
+    tokens = [ParsedToken(text, dep) for text, dep, _ in PARSED_TOKENS]
+    for token, (_, _, head) in zip(tokens, PARSED_TOKENS):
+        token.head = tokens[head]
+    return tokens
+
+
+def experiment_inputs():
+    """Seeded inputs of the experiment fixture: a 16 x 16 RGB image, a [5, 8, 8] global map, three ground-truth masks (one
+    name in mixed case, two names that ``simplify80`` folds onto the same coarse name), three predicted masks and a
+    composite index image."""
+    g = torch.Generator().manual_seed(91)
+    image = (torch.rand(16, 16, 3, generator=g) * 255).to(torch.uint8).numpy()
+    maps = torch.rand(5, 8, 8, generator=g)
+
+    def mask(p):
+        return (torch.rand(16, 16, generator=g) > p).float()
+    truth = {'Cat': mask(0.5), 'dog': mask(0.6), 'sky': mask(0.4)}
+    pred = {'cat': mask(0.5), 'Dog': mask(0.5), 'person': mask(0.7)}
+    composite = torch.randint(0, 4, (16, 16), generator=g).to(torch.uint8).numpy()
+    return image, maps, truth, pred, composite
+
+
+def run_experiment(daam):
+    """tests/golden/experiment_ref/ + experiment.npz: a directory WRITTEN BY the unmodified reference
+    (``GenerationExperiment.save`` / ``save_prediction_mask``, experiment.py:140-167,218-221) and what its own
+    ``GenerationExperiment.load`` reads back from it under the option sets below; evaluator results on fixed numbers; the
+    label tables.  Scaffolding: the composite index image is written here with PIL (the reference only reads it), and
+    ``torch.load`` of a pickled class needs TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD=1 under torch >= 2.6."""
+    import shutil
+    import PIL.Image
+    os.environ['TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD'] = '1'
+    ex = sys.modules['daam.experiment']
+    ev = sys.modules['daam.evaluate']
+    image, maps, truth, pred, composite = experiment_inputs()
+    shutil.rmtree(EXPERIMENT_DIR, ignore_errors=True)
+    exp = ex.GenerationExperiment(PIL.Image.fromarray(image), maps, 'a cat and a dog', seed=5, id='p7', path=EXPERIMENT_DIR,
+                                  truth_masks=truth, subtype='run')
+    exp.annotate('split', 'val').save(heat_maps=False)
+    for word, m in pred.items():
+        exp.save_prediction_mask(m, word, 'daam')
+    exp.save_prediction_mask(pred['cat'], 'cat', 'other')
+    PIL.Image.fromarray(composite).save(os.path.join(EXPERIMENT_DIR, 'p7', 'run', 'composite.comp.pred.png'))   # its own prefix: '*.daam.pred.png' would match it
+    out = {}
+    option_sets = {
+        'default': dict(),
+        'simplify80': dict(simplify80=True),
+        'composite': dict(pred_prefix='comp', composite=True, vocab=['floor', 'cat', 'dog', 'car']),
+        'composite_simplify80': dict(pred_prefix='comp', composite=True, simplify80=True, vocab=['floor', 'cat', 'dog', 'car']),
+        'composite_novocab': dict(pred_prefix='comp', composite=True),
+        'composite_missing': dict(pred_prefix='nothere', composite=True),
+        'other_prefix': dict(pred_prefix='other'),
+    }
+    for tag, kw in option_sets.items():
+        back = ex.GenerationExperiment.load(os.path.join(EXPERIMENT_DIR, 'p7'), subtype='run', **kw)
+        for kind, masks in (('truth', back.truth_masks), ('pred', back.prediction_masks)):
+            out[f'{tag}_{kind}_names'] = np.asarray(json.dumps(sorted(masks)))
+            for name, m in masks.items():
+                out[f'{tag}_{kind}_{name}'] = m.numpy()
+        assert back.annotations == {'split': 'val'} and back.prompt == 'a cat and a dog' and back.seed == 5
+        assert torch.equal(back.global_heat_map, maps)
+    out['option_sets'] = np.asarray(json.dumps(option_sets))
+    out['load_mask_cat'] = ev.load_mask(os.path.join(EXPERIMENT_DIR, 'p7', 'cat.gt.png')).numpy()
+    # evaluators: bookkeeping on IoUs supplied from outside (compute_iou swapped for a table look-up in the generator AND in
+    # the test; the IoU arithmetic itself is pinned by evaluate.npz)
+    table = {}
+
+    def fake_iou(a, b):
+        return table[(int(a.flatten()[0]), int(b.flatten()[0]))]
+    real = ev.compute_iou
+    ev.compute_iou = fake_iou
+    try:
+        rng = np.random.RandomState(5)
+        t = lambda v: torch.full((2, 2), float(v))             # noqa: E731
+        mean_ev, unsup = ev.MeanEvaluator(), ev.UnsupervisedEvaluator()
+        script = []
+        for i in range(12):
+            cands = [int(c) for c in rng.randint(0, 50, size=rng.randint(1, 4))]
+            truth_id = int(rng.randint(0, 5))
+            for c in cands:
+                table.setdefault((c, truth_id), float(rng.rand()))      # (a pair met again keeps its value)
+            gt_idx, pred_idx = int(rng.randint(0, 4)), int(rng.randint(0, 5))
+            script.append(dict(cands=cands, truth=truth_id, gt_idx=gt_idx, pred_idx=pred_idx, intensity=float(rng.rand())))
+            mean_ev.log_iou([t(c) for c in cands], t(truth_id)).log_intensity(t(script[-1]['intensity']))
+            unsup.log_iou([t(c) for c in cands], t(truth_id), gt_idx=gt_idx, pred_idx=pred_idx)
+            unsup.increment()
+        out['evaluator_script'] = np.asarray(json.dumps(script))
+        out['evaluator_table'] = np.asarray(json.dumps([[a, b, v] for (a, b), v in table.items()]))
+        out['mean_evaluator'] = np.asarray([mean_ev.mean_iou, mean_ev.ci95_miou, mean_ev.mean_intensity, len(mean_ev)], dtype=np.float64)
+        out['mean_evaluator_str'] = np.asarray(str(mean_ev))
+        out['unsupervised_evaluator'] = np.asarray([unsup.mean_iou, len(unsup)], dtype=np.float64)
+        out['unsupervised_evaluator_str'] = np.asarray(str(unsup))
+    finally:
+        ev.compute_iou = real
+    # parsed_heat_maps / dependency_relations (heatmap.py:125-142) over the stand-in parse (scaffolding: daam.heatmap.cached_nlp
+    # replaced by fake_parse; the reference's loops, lookups and skips run as they are)
+    hm = sys.modules['daam.heatmap']
+    real_nlp = hm.cached_nlp
+    hm.cached_nlp = fake_parse
+    try:
+        g = torch.Generator().manual_seed(92)
+        gmaps = torch.rand(10, 8, 8, generator=g)
+        ghm = hm.GlobalHeatMap(fd.FakeTokenizer(), PARSED_PROMPT, gmaps)
+        parsed = list(ghm.parsed_heat_maps())
+        rels = list(ghm.dependency_relations())
+        out['parsed_maps_in'] = gmaps.numpy()
+        out['parsed_tokens'] = np.asarray(json.dumps([p.token.text for p in parsed]))
+        out['parsed_maps'] = np.stack([p.word_heat_map.heatmap.numpy() for p in parsed])
+        out['relations'] = np.asarray(json.dumps([[r.head_text, r.dep_text, r.relation] for r in rels]))
+        out['relation_head_maps'] = np.stack([r.head_heat_map.heatmap.numpy() for r in rels])
+        out['relation_dep_maps'] = np.stack([r.dep_heat_map.heatmap.numpy() for r in rels])
+    finally:
+        hm.cached_nlp = real_nlp
+    out['labels'] = np.asarray(json.dumps(dict(coco80=ex.COCO80_LABELS, indices=ex.COCO80_INDICES, stuff27=ex.COCOSTUFF27_LABELS,
+                                               ontology=ex.COCO80_ONTOLOGY, to27=ex.COCO80_TO_27, unused=ex.UNUSED_LABELS,
+                                               word_list=ex.build_word_list_coco80())))
+    out['meta'] = np.asarray(json.dumps(dict(reference='castorini/daam v0.2.0 daam/experiment.py + daam/evaluate.py, executed unmodified',
+                                             torch=torch.__version__)))
+    path = os.path.join(OUT_DIR, 'experiment.npz')
+    np.savez_compressed(path, **out)
+    size = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(EXPERIMENT_DIR) for f in fs)
+    print(f'experiment: {len(option_sets)} option sets, {os.path.getsize(path) / 1e3:.1f} kB + directory {size / 1e3:.1f} kB')
+
+
 def main(argv):
     warnings.filterwarnings('ignore')
     torch.set_num_threads(os.cpu_count() or 1)
     daam, _ = fd.import_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
-    names = argv or list(CASES) + ['evaluate']
+    names = argv or list(CASES) + ['evaluate', 'experiment']
     for n in names:
         if n == 'evaluate':
             run_evaluate(daam)
+        elif n == 'experiment':
+            run_experiment(daam)
         else:
             run_case(n, CASES[n], daam)
 

@@ -87,3 +87,58 @@ def test_nan_prediction_gives_nan_like_the_reference():
     assert np.isnan(ho.compute_iou(a.numpy(), b.numpy()))
     a[3, 4] = 1.0
     assert abs(daam_amd.compute_iou(a.to(DEV), b.to(DEV)) - ho.compute_iou(a.numpy(), b.numpy())) <= 1e-6
+
+
+def test_evaluators_on_the_device():
+    """MeanEvaluator / UnsupervisedEvaluator (evaluate.py:46-117) over the kernel: the best candidate of a list scored in one
+    launch is the reference's max over ``compute_iou`` calls (golden IoUs), CPU masks and ragged candidate lists included."""
+    from daam_amd.evaluate import MeanEvaluator, UnsupervisedEvaluator, load_mask
+    z, _ = _golden()
+    name = 'binary_32_to_64'
+    a, b = torch.from_numpy(z[f'{name}_a']), torch.from_numpy(z[f'{name}_b'])
+    want = z[f'{name}_iou']
+    ev = MeanEvaluator()
+    for i in range(a.shape[0]):
+        ev.log_iou(a[i].to(DEV), b[i].to(DEV)).log_intensity(a[i].to(DEV))
+    np.testing.assert_allclose(ev.ious, want, rtol=0, atol=1e-7)
+    assert abs(ev.mean_iou - want.mean()) < 1e-7 and abs(ev.ci95_miou - 1.96 * want.std() / np.sqrt(len(want))) < 1e-7
+    assert abs(ev.mean_intensity - float(np.mean([a[i].mean() for i in range(a.shape[0])]))) < 1e-6 and len(ev) == a.shape[0]
+    # every prediction of the group as a candidate for truth 0 (CPU tensors: moved to the device), plus one of another size
+    import daam_amd
+    singles = [daam_amd.compute_iou(a[i], b[0]) for i in range(a.shape[0])]
+    big = torch.from_numpy(z['same_binary_64_a'][0])
+    singles.append(daam_amd.compute_iou(big, b[0]))
+    ev2 = MeanEvaluator().log_iou([a[i] for i in range(a.shape[0])] + [big], b[0])
+    assert ev2.ious == [max(singles)]
+    un = UnsupervisedEvaluator()
+    for gt in range(2):
+        for pred in range(2):
+            un.log_iou(a[pred].to(DEV), b[gt].to(DEV), gt_idx=gt, pred_idx=pred)
+        un.increment()
+    m = np.asarray([[daam_amd.compute_iou(a[p], b[g]) for p in range(2)] for g in range(2)])
+    assert abs(un.mean_iou - max(m[0, 0] + m[1, 1], m[0, 1] + m[1, 0]) / 2) < 1e-7 and len(un) == 2
+    # a mask file written by the reference, scored against itself
+    mask = load_mask(os.path.join(GOLDEN_DIR, 'experiment_ref', 'p7', 'cat.gt.png'))
+    assert abs(MeanEvaluator().log_iou(mask, mask).mean_iou - 1.0) < 1e-6
+
+
+def test_parsed_heat_maps_on_the_device():
+    """GlobalHeatMap.parsed_heat_maps / dependency_relations (heatmap.py:125-142) with the word maps from ``daam_word_heat_map``,
+    against what the unmodified reference produced over the same stand-in parse."""
+    import daam_amd
+    from daam_amd import utils
+    from oracle import fake_diffusers as fd
+    from oracle.make_golden import PARSED_PROMPT, fake_parse
+    z = np.load(os.path.join(GOLDEN_DIR, 'experiment.npz'))
+    utils.set_nlp(fake_parse)
+    try:
+        ghm = daam_amd.GlobalHeatMap(fd.FakeTokenizer(), PARSED_PROMPT, torch.from_numpy(z['parsed_maps_in']).to(DEV))
+        parsed = list(ghm.parsed_heat_maps())
+        assert [p.token.text for p in parsed] == json.loads(str(z['parsed_tokens']))
+        np.testing.assert_allclose(torch.stack([p.word_heat_map.heatmap for p in parsed]).cpu().numpy(), z['parsed_maps'], rtol=0, atol=1e-6)
+        rels = list(ghm.dependency_relations())
+        assert [[r.head_text, r.dep_text, r.relation] for r in rels] == json.loads(str(z['relations']))
+        np.testing.assert_allclose(torch.stack([r.head_heat_map.heatmap for r in rels]).cpu().numpy(), z['relation_head_maps'], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(torch.stack([r.dep_heat_map.heatmap for r in rels]).cpu().numpy(), z['relation_dep_maps'], rtol=0, atol=1e-6)
+    finally:
+        utils.set_nlp(None)
