@@ -39,6 +39,12 @@ ABLATE = int(os.environ.get('DAAM_PIPE_ABLATE', '0'))
 # chains back to back (c0 x4 | c1 x4 | a x2) with the VALU in three blocks behind them, 2 = 1 + s_setprio around the chains,
 # 3 half chains (pairs)
 SCHED = int(os.environ.get('DAAM_PIPE_SCHED', '0'))
+# experiment (tools/exp): time-sliced issue priority.  The two waves that share a SIMD come from different workgroups and the older
+# one wins the arbitration until it is done; with FAIR = b each wave raises its priority while bit b of the shader clock equals the
+# parity of its wave slot (input s46), so the two take turns.  0 = off (the shipped schedule).
+FAIR = int(os.environ.get('DAAM_PIPE_FAIR', '0'))
+S_TIME, S_TMP, S_PRIO_ID = '50:51', 52, 46
+_label = [0]
 NT = ' nt' if os.environ.get('DAAM_PIPE_NT') else ''     # cache policy of the plane fetches (every plane is read once)
 SLOT = 2048
 # ---- register map --------------------------------------------------------------------------------------------------
@@ -90,7 +96,18 @@ def dma(base):
             f's_add_u32 s{S_DMASLOT}, s{S_DMASLOT}, {SLOT}', f's_and_b32 s{S_DMASLOT}, s{S_DMASLOT}, {R * SLOT - 1}']
 
 def next_key():
-    return [f's_load_dwordx2 s[{S_BASE}], s[{S_KEYS}], s{S_KOFF}', f's_add_u32 s{S_KOFF}, s{S_KOFF}, 8']
+    return ([f's_load_dwordx2 s[{S_BASE}], s[{S_KEYS}], s{S_KOFF}', f's_add_u32 s{S_KOFF}, s{S_KOFF}, 8'] +
+            ([f's_memtime s[{S_TIME}]'] if FAIR else []))
+
+
+def take_turns():
+    """behind the lgkmcnt(0) that also returned the clock read: priority 1 while clock bit FAIR == this wave's slot parity"""
+    if not FAIR:
+        return []
+    _label[0] += 1
+    n = _label[0]
+    return [f's_lshr_b32 s{S_TMP}, s{S_TIME.split(":")[0]}, {FAIR}', f's_xor_b32 s{S_TMP}, s{S_TMP}, s{S_PRIO_ID}', f's_bitcmp1_b32 s{S_TMP}, 0',
+            f's_cbranch_scc1 L_hi{n}_%=', 's_setprio 0', f's_branch L_pd{n}_%=', f'L_hi{n}_%=:', 's_setprio 1', f'L_pd{n}_%=:']
 
 def read_plane():
     """after the caller's vmcnt wait: the partner's half has landed once both waves are past the barrier"""
@@ -136,7 +153,7 @@ def iteration(pi, do_c=True, do_d=True, do_b=True, do_a=True, do_dma=True):
         # the plane DMA (behind the lgkmcnt(0) that retires this iteration's plane reads and last iteration's key load) and
         # the next key load: inside VALU blocks, never between the MFMAs of a chain
         if do_dma and do_c and gi == (5 if SCHED == 0 else 3):
-            L += ['s_waitcnt lgkmcnt(0)'] + dma(S_BASE)
+            L += ['s_waitcnt lgkmcnt(0)'] + take_turns() + dma(S_BASE)
         if do_dma and do_c and gi == (6 if SCHED == 0 else 7):
             L += next_key()
         if SCHED != 0 and ABLATE == 1 and do_c and do_a and gi == 3:
@@ -176,7 +193,7 @@ def build():
     L += iteration(0, do_a=False, do_dma=False)
     L += iteration(1, do_a=False, do_b=False, do_dma=False)
     L += ['s_nop 15', 's_nop 15'] + stage_D(1)
-    L += ['s_waitcnt vmcnt(0)', f's_mov_b32 m0, s{S_M0SAVE}']
+    L += ['s_waitcnt vmcnt(0)', f's_mov_b32 m0, s{S_M0SAVE}'] + (['s_setprio 0'] if FAIR else [])
     return L
 
 
@@ -200,7 +217,7 @@ def main():
          [f'"s{r}"' for r in [S_M0SAVE] + list(range(S_PRE, S_PRE + 2 * R))] + ['"memory"', '"scc"'])
     lines = build()
     used_v = sorted(set(range(P[0], GOFF)) - set(range(ASET(0), ASET(0) + 64))) + [LDS_TMP]
-    clob = [f'"v{r}"' for r in used_v] + [f'"s{r}"' for r in [S_KOFF, 40, 41, S_RDSLOT, S_DMASLOT, 45, S_M0SAVE]]
+    clob = [f'"v{r}"' for r in used_v] + [f'"s{r}"' for r in [S_KOFF, 40, 41, S_RDSLOT, S_DMASLOT, 45, S_M0SAVE] + ([50, 51, S_TMP] if FAIR else [])]
     clob += ['"memory"', '"scc"', '"vcc"']
     emit(os.path.join(here, f'daam_finalize_pipe_asm_r{R}.inc' if not (ABLATE or os.environ.get('DAAM_PIPE_OUT')) else (os.environ.get('DAAM_PIPE_OUT') or f'daam_finalize_pipe_asm_abl{ABLATE}.inc')),
          ['// GENERATED by tools/gen_fin_pipe.py -- do not edit; the schedule and its hazard distances are documented there.',
@@ -209,7 +226,7 @@ def main():
          lines,
          '"+{v[144:159]}"(accA0), "+{v[160:175]}"(accA1), "={v[176:191]}"(accB0), "={v[192:207]}"(accB1), "+{s39}"(trips)',
          '"{v[0:3]}"(wx0), "{v[4:7]}"(wx1), "{v[8:11]}"(wy00), "{v[12:15]}"(wy01), "{v[16:19]}"(wy10), "{v[20:23]}"(wy11),\n'
-         '      "{v208}"(goff), "{v210}"(lds_rd), "{s[36:37]}"(key_ptrs), "{s42}"(ring_half)', clob)
+         '      "{v208}"(goff), "{v210}"(lds_rd), "{s[36:37]}"(key_ptrs), "{s42}"(ring_half)' + (', "{s46}"(prio_id)' if FAIR else ''), clob)
     per_iter = iteration(0)
     print('wrote', here, len(pre), '+', len(lines), 'instructions;', 'steady iteration:', len(per_iter), 'instructions,',
           sum(1 for l in per_iter if l.startswith('v_mfma')), 'MFMA')
