@@ -45,6 +45,7 @@ hipError_t launch_mask_overlap(const float*, int, int, const float*, int, int, i
 bool attend_d64_supported(int in_dtype, int head_dim, int tokens, const int64_t* strides, int n_strides, const void* const* ptrs, int n_ptrs);
 hipError_t launch_attend_d64(const AttendLaunch&, int in_dtype, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
 hipError_t launch_clock_monitor(unsigned long long* samples, int n_samples, int period_us, hipStream_t);
+hipError_t launch_start_gate(const unsigned* counter, unsigned target, int timeout_us, hipStream_t);
 constexpr int kClockMaxSamples = 4096;
 hipError_t launch_word(const float*, int, const int32_t*, int, float*, float*, int, int, int, float, float*,
                        hipStream_t);
@@ -212,6 +213,9 @@ struct DaamCtx {
     static constexpr int kAux = 3;     // side streams of multi-kind tap flushes (see daam_tap_flush)
     hipStream_t aux_stream[kAux] = {nullptr, nullptr, nullptr};
     hipEvent_t aux_fork = nullptr, aux_join[kAux] = {nullptr, nullptr, nullptr};
+    unsigned* d_started = nullptr;     // start gate of multi-kernel flushes: workgroups of side kernels started so far (wraps)
+    unsigned started_target = 0;       // ... and how many the host has launched
+    int no_start_gate = 0;             // debugging / A-B: DAAM_NO_START_GATE=1
     int no_side_stream = 0;
 
     int force_generic = 0;
@@ -320,6 +324,11 @@ static hipError_t ensure_aux(DaamCtx* c)
         ae = hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking);
         if (ae == hipSuccess) ae = hipEventCreateWithFlags(&c->aux_join[i], hipEventDisableTiming);
     }
+    if (ae == hipSuccess && !c->d_started) {
+        ae = hipMalloc(reinterpret_cast<void**>(&c->d_started), sizeof(unsigned));
+        if (ae == hipSuccess) ae = hipMemset(c->d_started, 0, sizeof(unsigned));
+        c->started_target = 0;
+    }
     return ae;
 }
 
@@ -359,6 +368,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->no_mfma_finalize = nm && nm[0] == '1';
     const char* nfs = getenv("DAAM_NO_FOLD_SAME");
     c->no_fold_same = nfs && nfs[0] == '1';
+    const char* nsg = getenv("DAAM_NO_START_GATE");
+    c->no_start_gate = nsg && nsg[0] == '1';
     const char* npp = getenv("DAAM_NO_PIPE_FINALIZE");
     c->no_pipe_finalize = npp && npp[0] == '1';
     const char* npf = getenv("DAAM_NO_PAIRED_FINALIZE");
@@ -390,6 +401,7 @@ int daam_ctx_destroy(DaamCtx* c)
         for (auto& ev : pair)
             if (ev) (void)hipEventDestroy(ev);
     if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
+    if (c->d_started) (void)hipFree(c->d_started);
     for (auto& ev : c->aux_join)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& st : c->aux_stream)
@@ -865,13 +877,24 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         if (!forked || i != main_idx) launch_order.push_back(i);
     if (forked && !main_first) launch_order.push_back(main_idx);
     int n_side = 0;
+    // start gate: the side kernels' workgroups count themselves in, the main kernel waits (one wave, bounded) until they are
+    // resident -- only for the kernels that carry the counter (the MFMA kinds)
+    bool gate = forked && !main_first && !c->no_start_gate && c->d_started;
+    for (size_t i = 0; i < prepared.size(); ++i)
+        if (i != main_idx && !prepared[i].kd) gate = false;
+    unsigned gate_wgs = 0;
     for (size_t pi : launch_order) {
         if (rc) break;
-        const Prepared& pr = prepared[pi];
+        Prepared& pr = prepared[pi];
         hipStream_t ks = s;
         if (forked && pi != main_idx) {
             ks = c->aux_stream[n_side];
             if (hipStreamWaitEvent(ks, c->aux_fork, 0) != hipSuccess) { rc = fail(DAAM_E_STATE, "stream fork failed"); break; }
+            if (gate) { pr.L.started = c->d_started; gate_wgs += (unsigned)pr.L.total_wgs; }
+        } else if (gate && gate_wgs) {
+            c->started_target += gate_wgs;                     // unsigned wrap-around is fine: the kernel compares differences
+            hipError_t ge = launch_start_gate(c->d_started, c->started_target, 200, s);
+            if (ge != hipSuccess) { rc = fail((int)ge, "start gate: %s", hipGetErrorString(ge)); break; }
         }
         int grid = 0;
         hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, ks, &grid, &c->last_lds[0])
@@ -994,6 +1017,8 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     const size_t plane = (size_t)c->out_side * c->out_side;
     const size_t out_bytes = sizeof(float) * c->tokens * plane;
     static const int env_chunks = getenv("DAAM_FIN_CHUNKS") ? atoi(getenv("DAAM_FIN_CHUNKS")) : 0;
+    static const int env_up_chunks = getenv("DAAM_FIN_UP_CHUNKS") ? atoi(getenv("DAAM_FIN_UP_CHUNKS")) : 0;       // LDS up kernels only (A/B)
+    static const int env_pipe_chunks = getenv("DAAM_FIN_PIPE_CHUNKS") ? atoi(getenv("DAAM_FIN_PIPE_CHUNKS")) : 0; // pipelined x2 kernel only (A/B)
     // x2 class on the matrix cores (fp16 planes, fp16-exact tap matrix)?
     const bool mfma_up = !keys[1].empty() && c->acc_dtype == DAAM_F16 && keys[1][0].tab == c->up32_tab && c->d_up32_ops &&
                          c->tab_fp16_exact[keys[1][0].tab] && !c->no_mfma_finalize;
@@ -1004,7 +1029,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     int pipe_chunks = 0, pipe_nk = 0, pipe_stride = 0;
     if (pipe_up) {
         const int n = (int)keys[1].size();
-        const int want = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
+        const int want = env_pipe_chunks ? env_pipe_chunks : env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
         pipe_chunks = std::max(1, std::min(want, (n + 7) / 8));
         const int per = (n + pipe_chunks - 1) / pipe_chunks;
         pipe_nk = std::max(4, (per + 1) & ~1);
@@ -1050,8 +1075,10 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     constexpr int kFinMfmaKeysPerLaunch = kFinMaxChunks * 128;
     // x2 class chunking: ~1000 workgroups (one full round at 4 workgroups per CU) measured best -- fewer leaves a ragged
     // tail, more pays the per-workgroup reduction + atomics too often; every key lane of a chunk takes at most 64 keys
-    const int want_up = env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
-    auto up_chunks = [&](int n) { return std::max(std::max(1, std::min((n + 3) / 4, want_up)), (n + 127) / 128); };
+    const int want_up = env_up_chunks ? env_up_chunks : env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
+    // (few keys: at least 4 per wave -- a workgroup ends in a four-wave LDS reduction + 4096 atomics, which one key per wave does
+    // not pay for: SD-v1.5's 48 x4 keys in 3 chunks instead of 12 take 10 us less)
+    auto up_chunks = [&](int n) { return std::max(std::max(1, std::min((n + 15) / 16, want_up)), (n + 127) / 128); };
     // build the launch descriptor of every non-empty class first
     FinLaunch launches[kClasses];
     bool have[kClasses] = {false, false, false, false, false};

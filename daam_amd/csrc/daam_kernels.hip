@@ -545,6 +545,28 @@ hipError_t launch_clock_monitor(unsigned long long* samples, int n_samples, int 
     return hipGetLastError();
 }
 
+// Start gate of a multi-kernel tap flush (SD-v1.5: head_dim 40 / 80 / 160 = three kernels).  The small kernels run on side
+// streams behind an event wait, the large one on the caller's stream -- and when the large one's 1024 workgroups are dispatched
+// first they take every CU's LDS for their whole 50-step life and the small kernels only start when they drain (measured: 495 us
+// per flush against 435 us when the small kernels' workgroups are resident first and the large grid fills in around them).  One
+// wave on the caller's stream, ahead of the large kernel: wait until the side kernels' workgroups have counted themselves in
+// (TapLaunch::started), or for `timeout_us` -- it holds no LDS and one wave slot, so it can never keep them from starting.
+__global__ __launch_bounds__(64) void start_gate_kernel(const unsigned* counter, unsigned target, int timeout_us)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();                 // 100 MHz
+    const unsigned long long limit = (unsigned long long)timeout_us * 100ull;
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+
+hipError_t launch_start_gate(const unsigned* counter, unsigned target, int timeout_us, hipStream_t stream)
+{
+    hipLaunchKernelGGL(start_gate_kernel, dim3(1), dim3(64), 0, stream, counter, target, timeout_us);
+    return hipGetLastError();
+}
+
 hipError_t launch_normalize(float* maps, int n_rows, int plane, hipStream_t stream)
 {
     hipLaunchKernelGGL(normalize_kernel, dim3((plane + 255) / 256), dim3(256), 0, stream, maps, n_rows, plane);

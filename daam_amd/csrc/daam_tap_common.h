@@ -23,6 +23,11 @@ __device__ __forceinline__ int mfma_logical_block(int total_wgs, int wgs_per_xcd
     return l < total_wgs ? l : -1;
 }
 
+// start gate of a multi-kernel flush: a side kernel's workgroups count themselves in (see start_gate_kernel, daam_kernels.hip)
+__device__ __forceinline__ void tap_mark_started(const TapLaunch& L) {
+    if (L.started && threadIdx.x == 0) __hip_atomic_fetch_add(L.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ int mfma_find_layer(const DAAM_GLOBAL TapLayer* layers, int n, int wg) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {

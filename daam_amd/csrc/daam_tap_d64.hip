@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
 
     const int wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
     if (wg < 0) return;
+    tap_mark_started(L);
     TapLayer lay;
     const bool table = L.layers != nullptr;
     if (table) {
@@ -188,7 +189,6 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     // Fetches are raw buffer loads: address = the step's tensor (a wave-uniform resource descriptor built from the pointer
     // in SGPRs) + a per-lane 32-bit byte offset that never changes + a wave-uniform byte offset.  No 64-bit address
     // arithmetic on the VALU (7 v_lshl_add_u64 per wave-step with plain global loads), offsets stay single registers.
-    typedef int int4v __attribute__((ext_vector_type(4)));
     auto tensor = [](const void* p) -> __amdgpu_buffer_rsrc_t {
         const unsigned long long v = reinterpret_cast<unsigned long long>(p);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(qtile + i * 1024), 16, qd_src[i & 1], q_s[i], 0, DAAM_TAP_Q_AUX);
     };
 #endif
-    // one denoising step: logits of step s from the K and Q tiles in LDS, then the fetches of step s + 1 into registers,
-    // softmax + accumulate of the two pixel groups, K and Q of step s + 1 into LDS (K: the other buffer; Q: this wave's
-    // own tile, whose reads are behind it)
+    // one denoising step: logits of step s from the K and Q tiles in LDS, then the fetches of the next step (head_dim 64: by DMA
+    // into the other K buffer / this wave's own Q tile, whose reads are behind it; head_dim < 64: step s + 1 from the staging
+    // registers into LDS and the request for step s + 2), softmax + accumulate of the two pixel groups
     auto step = [&](int s) {
 #if !defined(DAAM_TAP_ABLATE) || DAAM_TAP_ABLATE != 1         // timing experiment 1: no per-step barrier (results are wrong)
         __syncthreads();
@@ -289,8 +289,14 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             dma_k(min(s + 1, n_steps - 1), (s + 1) & 1);
             dma_q(min(s + 1, n_steps - 1));
         } else {
-            issue_k(min(s + 1, n_steps - 1));
-            issue_q(min(s + 1, n_steps - 1));
+            // head_dim < 64 (register-staged): the pieces of step s + 1 were requested a whole step ago -- into LDS now (K buffer
+            // (s + 1) & 1 was last read in step s - 1, which every wave left before this step's barrier; the Q tile is this wave's
+            // own and its operand reads are behind it), then the request for step s + 2 goes out: a fetch has a whole step to
+            // land instead of one softmax (SD-v1.5's 64 x 64 layers: 330 -> 285 us per 50-step launch)
+            commit_k((s + 1) & 1);
+            commit_q();
+            issue_k(min(s + 2, n_steps - 1));                 // branch-free: the last steps re-fetch the last one
+            issue_q(min(s + 2, n_steps - 1));
         }
 #elif defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 2           // timing experiment 2: every step re-reads step 0 (cache-resident)
         issue_k(0);
@@ -309,9 +315,6 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
 #if DAAM_TAP_DMA
         if constexpr (FULL64) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs have landed; the next step's barrier publishes K
-        } else {
-            commit_k((s + 1) & 1);
-            commit_q();
         }
 #else
         commit_k((s + 1) & 1);
@@ -328,6 +331,8 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         issue_q(0);
         commit_k(0);
         commit_q();
+        issue_k(min(1, n_steps - 1));
+        issue_q(min(1, n_steps - 1));
     }
 #else
     issue_k(0);

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T, FAST_EXP>())) v
 
     const int wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
     if (wg < 0) return;
+    tap_mark_started(L);
     TapLayer lay;
     const bool table = L.layers != nullptr;
     if (table) {

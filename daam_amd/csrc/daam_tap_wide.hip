@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, (KS > 3 ? 1 : 2)) void tap_wide_kernel(const T
 
     const int wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
     if (wg < 0) return;
+    tap_mark_started(L);
     TapLayer lay;
     const bool table = L.layers != nullptr;
     if (table) {
@@ -140,7 +141,6 @@ __global__ __launch_bounds__(256, (KS > 3 ? 1 : 2)) void tap_wide_kernel(const T
     unsigned char* qtile = kbuf + S::kQOff + wave * S::kQTile;
     const int f_rd = j * S::kRow + h * 16;                    // operand reads: row l&15 of a 16-row tile, chunk 4 ks + (l >> 4)
 
-    typedef int int4v __attribute__((ext_vector_type(4)));
     auto tensor = [](const void* p) -> __amdgpu_buffer_rsrc_t {
         const unsigned long long v = reinterpret_cast<unsigned long long>(p);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));

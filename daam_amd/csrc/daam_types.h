@@ -57,6 +57,8 @@ struct TapLaunch {
     int32_t tokens;
     int32_t total_wgs;      // logical workgroups (grid is rounded up to a multiple of 8 XCDs)
     int32_t wgs_per_xcd;    // ceil(total_wgs / 8)
+    unsigned* started;      // NULL, or a counter every (logical) workgroup bumps when it starts: the start gate of a multi-kernel
+                            // flush (daam_tap_flush) holds the large kernel back until the small ones' workgroups are resident
     TapLayer one;
     TapPtr one_ptr;
 };
