@@ -208,7 +208,7 @@ def test_sd15_full_stack_50_steps_three_kernels_side_by_side(sd15_stack, monkeyp
     tap_d64_kernel with zero padding, 80 -> tap_wide_kernel<3>, 160 -> tap_wide_kernel<5>), the two small ones on auxiliary
     streams forked from / joined to the caller's stream.  The whole stack against the reference's processor on the same
     inputs (120 keys: every one compared), then the same generation with every kernel on the caller's stream
-    (DAAM_NO_SIDE_STREAM=1): bit-identical running sums."""
+    (DAAM_NO_SIDE_STREAM=1) and side by side without the start gate (DAAM_NO_START_GATE=1): bit-identical running sums."""
     from daam_amd import engine as E
     pipe = sd15_stack
     steps = 50
@@ -229,6 +229,15 @@ def test_sd15_full_stack_50_steps_three_kernels_side_by_side(sd15_stack, monkeyp
     assert serial['flush'] == dict(kernels=3, side_streams=0, max_steps=steps, launches=1), serial['flush']
     for key in got['raw']:
         assert torch.equal(got['raw'][key], serial['raw'][key]), key
+    E.release_parked_contexts()
+    # ... and side by side without the start gate (the one wave that holds the large kernel back until the small kernels'
+    # workgroups are resident: launch ORDER only, the same three kernels)
+    monkeypatch.delenv('DAAM_NO_SIDE_STREAM')
+    monkeypatch.setenv('DAAM_NO_START_GATE', '1')
+    ungated = _traced_generation(pipe, prompt, steps, sample, defer_steps=64)
+    assert ungated['flush'] == dict(kernels=3, side_streams=2, max_steps=steps, launches=1), ungated['flush']
+    for key in got['raw']:
+        assert torch.equal(got['raw'][key], ungated['raw'][key]), key
     E.release_parked_contexts()
 
 
