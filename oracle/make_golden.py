@@ -79,6 +79,10 @@ CASES = {
                                  unet=dict(dim_head=16, upcast_attention=True), variants=['default', 'normalize']),
     'sd15_upcast_softmax_f16': dict(kind='sd15', dtype='float16', batch=2, steps=4, prompt='a dog', seed=22,
                                     unet=dict(dim_head=16, upcast_softmax=True), variants=['default']),
+    # SD-v1.5 at its REAL layer shapes (mini=False: 8 heads x head_dim 40 / 80 / 160 = 320 / 640 / 1280 channels at 64 / 32 / 16
+    # squared): the unmodified reference on the shapes whose taps run as three kernels side by side (BASELINE configs[1])
+    'sd15_real_f16': dict(kind='sd15', dtype='float16', batch=2, steps=3, prompt='a dog', seed=23, mini=False,
+                          unet=dict(), variants=['default', 'normalize', 'factor_hi', 'factor_lo', 'layer_head']),
 }
 
 SAMPLE_TOKENS = [0, 1, 2, 76]
@@ -121,7 +125,7 @@ def run_case(name, spec, daam):
     import tempfile
     dtype = getattr(torch, spec['dtype'])
     pipe = fd.make_pipe(spec['kind'], dtype=dtype, batch=spec['batch'], seed=spec['seed'],
-                        mini=True, identity_proj=True, **spec['unet'])
+                        mini=spec.get('mini', True), identity_proj=True, **spec['unet'])
     pipe.keep_outputs = True
     out = {}
     heads_dir = tempfile.mkdtemp(prefix='daam_heads_') if spec.get('heads') else None
@@ -196,7 +200,7 @@ def run_case(name, spec, daam):
         # replay: a pipeline with OTHER hidden states (seed + 100) under load_heads=True reads the saved probabilities
         # back, so its maps equal the ones above and its attention outputs are the saved probabilities x its own V
         pipe2 = fd.make_pipe(spec['kind'], dtype=dtype, batch=spec['batch'], seed=spec['seed'] + 100,
-                             mini=True, identity_proj=True, **spec['unet'])
+                             mini=spec.get('mini', True), identity_proj=True, **spec['unet'])
         pipe2.keep_outputs = True
         with daam.trace(pipe2, load_heads=True, data_dir=heads_dir) as tc2:
             pipe2(spec['prompt'], num_inference_steps=spec['steps'])
