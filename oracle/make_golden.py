@@ -83,6 +83,9 @@ CASES = {
     # squared): the unmodified reference on the shapes whose taps run as three kernels side by side (BASELINE configs[1])
     'sd15_real_f16': dict(kind='sd15', dtype='float16', batch=2, steps=3, prompt='a dog', seed=23, mini=False,
                           unet=dict(), variants=['default', 'normalize', 'factor_hi', 'factor_lo', 'layer_head']),
+    # SDXL at its real layer shapes (60 tapped layers: 5 / 10 / 20 heads x head_dim 64, 1100 keys; BASELINE configs[2], the headline)
+    'sdxl_real_f16': dict(kind='sdxl', dtype='float16', batch=2, steps=2, prompt='a dog', seed=24, mini=False,
+                          unet=dict(), variants=['default', 'normalize', 'factor_hi']),
 }
 
 SAMPLE_TOKENS = [0, 1, 2, 76]

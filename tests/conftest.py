@@ -33,7 +33,8 @@ def golden_pipe(meta, device='cpu', seed_offset=0):
 
 
 GOLDEN_CASES = ['sd15_f32', 'sd15_f16', 'sd15_bf16', 'sdxl_f32', 'sdxl_f16', 'sdxl2048_f32', 'sd15_nocfg_f32', 'sd15_b4_f32',
-                'sdxl_heads_f32', 'sd15_heads_f16', 'sd15_upcast_attn_f16', 'sd15_upcast_softmax_f16', 'sd15_real_f16']
+                'sdxl_heads_f32', 'sd15_heads_f16', 'sd15_upcast_attn_f16', 'sd15_upcast_softmax_f16', 'sd15_real_f16',
+                'sdxl_real_f16']
 
 
 @pytest.fixture(params=GOLDEN_CASES)
