@@ -365,16 +365,26 @@ def _respawn_under_launcher(n, shared_device):
 
 
 def load_profile(name):
-    """A committed profiler summary (profiles/<name>) if it was measured on THIS build of the kernels, else None."""
-    from daam_amd.build import csrc_sha
+    """A committed profiler summary (profiles/<name>) if it was measured on THIS build of the kernels, else None.  "This build":
+    the same kernel sources (``csrc_sha``), or -- when sources were added / gained compiled-out experiments since -- every kernel of
+    the measured build byte-identical in this one (``kernel_shas`` in the file against ``daam_amd.build.kernel_shas()``)."""
+    from daam_amd.build import csrc_sha, kernel_shas
     path = os.path.join(ROOT, 'profiles', name)
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None, None
-    if rec.get('csrc_sha') != csrc_sha():
-        return None, f'profiles/{name} was measured on kernel sources {rec.get("csrc_sha")}, this build is {csrc_sha()}'
-    return rec, f'profiles/{name} (rocprofv3 --pmc passes of this build, csrc {rec["csrc_sha"]}; not re-measured in this run)'
+    if rec.get('csrc_sha') == csrc_sha():
+        return rec, f'profiles/{name} (rocprofv3 --pmc passes of this build, csrc {rec["csrc_sha"]}; not re-measured in this run)'
+    want = rec.get('kernel_shas')
+    if want:
+        have = kernel_shas()
+        changed = [k for k, v in want.items() if have.get(k) != v]
+        if not changed:
+            return rec, (f'profiles/{name} (rocprofv3 --pmc passes of csrc {rec["csrc_sha"]}; this build is csrc {csrc_sha()} with all '
+                         f'{len(want)} kernels of that build byte-identical; not re-measured in this run)')
+        return None, f'profiles/{name} was measured on kernel sources {rec.get("csrc_sha")}; {len(changed)} of its kernels differ in this build ({csrc_sha()})'
+    return None, f'profiles/{name} was measured on kernel sources {rec.get("csrc_sha")}, this build is {csrc_sha()}'
 
 
 COUNTER_FILES = ('r03_counters.json', 'r02_counters.json')      # newest first; only one matching this build is used
@@ -544,13 +554,19 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     key = f'{name}:defer{spl}:{args.accumulate}'
     prof, prof_note = load_counters()
     rec = (prof or {}).get('workloads', {}).get(key)
+    if rec and rec.get('tap_kernels_per_launch', flush['kernels']) != flush['kernels']:
+        # the committed counters are of another launch structure (SD-v1.5: three kernels side by side; now one chunked kernel)
+        prof_note = (f'profiles: the committed PMC pass of {key} is of a {rec["tap_kernels_per_launch"]}-kernel launch, this run launches '
+                     f'{flush["kernels"]}: {rec.get("tap_note", "not comparable")}')
+        rec = {k: v for k, v in rec.items() if not k.startswith('tap_')}
     traffic = rec.get('tap_bytes_per_launch') if rec else None
     tap_kernel = ('tap_d64_kernel (16x16x32 MFMA tiles, head_dim 64)' if wl['kind'] == 'sdxl'
+                  else 'tap_chunk_kernel (head_dim 40 / 80 / 160 in 64-element chunks, every layer in ONE launch)' if flush['kernels'] == 1
                   else 'tap_d64_kernel (head_dim 40) + tap_wide_kernel<3|5> (head_dim 80 / 160), one flush = 3 kernels side by side')
     out['roofline'] = dict(bound='hbm', kernel=tap_kernel,
                            achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
                            traffic=traffic, traffic_measured_in_run=False,
-                           traffic_source=prof_note if rec else (prof_note or 'no PMC pass committed for this workload'),
+                           traffic_source=prof_note if traffic is not None else (prof_note or 'no PMC pass committed for this workload'),
                            bytes_per_launch=int(bytes_launch), ms_per_launch=round(tap_ms_avg, 4),
                            steps_per_launch=spl, launches_per_generation=launches_per_gen,
                            kernels_per_launch=flush['kernels'], kernels_on_side_streams=flush['side_streams'],

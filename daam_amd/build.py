@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['daam_api.hip', 'daam_kernels.hip', 'daam_tap_mfma.hip', 'daam_tap_d64.hip', 'daam_tap_wide.hip', 'daam_attend_d64.hip', 'daam_finalize.hip', 'daam_finalize_pipe.hip']
+SOURCES = ['daam_api.hip', 'daam_kernels.hip', 'daam_tap_mfma.hip', 'daam_tap_d64.hip', 'daam_tap_wide.hip', 'daam_tap_chunk.hip', 'daam_attend_d64.hip', 'daam_finalize.hip', 'daam_finalize_pipe.hip']
 HEADERS = ['daam_types.h', 'daam_tap_common.h', 'daam_tap16.h', 'daam_tap16_softmax.h', 'daam_finalize_pipe_asm_r16.inc', 'daam_finalize_pipe_prefill_r16.inc', 'daam_finalize_pipe_asm_r8.inc', 'daam_finalize_pipe_prefill_r8.inc', os.path.join('..', '..', 'include', 'daam_hip.h')]
 OUT = os.path.join(HERE, 'libdaam_hip.so')
 
@@ -21,6 +21,56 @@ def csrc_sha() -> str:
         with open(os.path.join(HERE, 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
+
+
+def kernel_shas(lib: str = OUT) -> dict:
+    """``{mangled kernel name: fingerprint of its machine code}`` for every kernel in a built library: the gfx950 code objects
+    are cut out of the offload bundles in ``.hip_fatbin`` and the bytes of every function symbol hashed.  Unlike ``csrc_sha``
+    this does not change when a source file gains an ``#if``-guarded experiment or when another kernel file is added, and it
+    does change when the compiler emits different code for an untouched source: it is what ties a committed profiler summary to
+    the kernels of THIS build (bench.py ``load_counters``)."""
+    import hashlib
+    import struct
+    data = open(lib, 'rb').read()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    out = {}
+    pos = data.find(magic)
+    while pos >= 0:
+        n, = struct.unpack_from('<Q', data, pos + len(magic))
+        o = pos + len(magic) + 8
+        for _ in range(n):
+            off, size, ts = struct.unpack_from('<QQQ', data, o)
+            o += 24
+            triple = data[o:o + ts].decode()
+            o += ts
+            if 'gfx950' in triple and size:
+                out.update(_elf_function_shas(data[pos + off:pos + off + size], hashlib))
+        pos = data.find(magic, pos + 1)
+    return out
+
+
+def _elf_function_shas(elf: bytes, hashlib) -> dict:
+    import struct
+    if elf[:4] != b'\x7fELF' or elf[4] != 2:
+        return {}
+    shoff, = struct.unpack_from('<Q', elf, 0x28)
+    shentsize, shnum, _ = struct.unpack_from('<HHH', elf, 0x3A)
+    secs = [struct.unpack_from('<IIQQQQIIQQ', elf, shoff + i * shentsize) for i in range(shnum)]
+    out = {}
+    for (_, typ, _, _, off, size, link, _, _, entsize) in secs:
+        if typ != 2:                                         # SHT_SYMTAB
+            continue
+        str_off = secs[link][4]
+        for i in range(size // entsize):
+            name_i, info, _, shndx, value, fsize = struct.unpack_from('<IBBHQQ', elf, off + i * entsize)
+            if (info & 0xF) != 2 or not fsize or shndx >= len(secs):      # STT_FUNC with a body
+                continue
+            end = elf.index(b'\0', str_off + name_i)
+            name = elf[str_off + name_i:end].decode()
+            sec = secs[shndx]
+            start = sec[4] + (value - sec[3])
+            out[name] = hashlib.sha256(elf[start:start + fsize]).hexdigest()[:12]
+    return out
 
 
 def hipcc() -> str:

@@ -28,6 +28,9 @@ bool tap_wide_supported(int in_dtype, int head_dim, int hw, int64_t q_sp, int64_
 hipError_t launch_tap_wide(const TapLaunch&, int acc_dtype, int max_head_dim, int fast_exp, hipStream_t, int*, int*);
 bool tap_d64_supported(int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                        const void* q, const void* k);
+bool tap_chunk_supported(int in_dtype, int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
+                         int64_t q_extent, const void* q, const void* k);
+hipError_t launch_tap_chunk(const TapLaunch&, int acc_dtype, int fast_exp, int interleave, hipStream_t, int*, int*);
 
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
@@ -221,6 +224,8 @@ struct DaamCtx {
     int force_generic = 0;
     int fast_exp = 0;
     int no_d64 = 0;
+    int tap_chunked = 2;              // tap_chunk_kernel (fp16 layers of any head_dim, one kind of workgroup): 2 = for deferred launches that
+                                      // mix head dims (default), 1 = for every fp16 layer (DAAM_TAP_CHUNKED=1), 0 = never (DAAM_TAP_CHUNKED=0)
 };
 
 // Entry points may be called with another device current (a pipeline on cuda:1 while the process default is
@@ -378,6 +383,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->no_d64 = n16 && n16[0] == '1';
     const char* nss = getenv("DAAM_NO_SIDE_STREAM");        // debugging / A-B: every tap kernel of a flush on the caller's stream
     c->no_side_stream = nss && nss[0] == '1';
+    const char* tck = getenv("DAAM_TAP_CHUNKED");           // daam_tap_chunk.hip: unset = launches that mix head dims, 1 = always, 0 = never
+    c->tap_chunked = !tck || !tck[0] ? 2 : tck[0] == '1' ? 1 : tck[0] == '0' ? 0 : 2;
 
     // softmax flavour of the MFMA tap: fast (default; exponent by one mixed-precision FMA, ~1e-6 relative,
     // same deviation class as the f32 summation order of q.k -- DESIGN.md section 3.1) or compensated
@@ -607,9 +614,24 @@ static bool use_wide(const DaamCtx* c, const DaamQKDesc& d, const void* q, const
                               d.k_stride_h, q, k);
 }
 
+// the chunked kernel (daam_tap_chunk.hip) takes this call: fp16 layers of any head_dim (multiple of 8, <= 256)
+static bool chunk_ok(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
+{
+    return c->tap_chunked && !c->no_d64 && (c->acc_dtype == DAAM_F16 || c->acc_dtype == DAAM_F32) && d.tokens == 77 &&
+           tap_chunk_supported(d.in_dtype, d.head_dim, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h, d.k_stride_b,
+                               d.k_stride_h, (int64_t)d.batch * d.q_stride_b, q, k);
+}
+
+// DAAM_TAP_CHUNKED=1: every such call; by default only the deferred launches that mix head dims (daam_tap_flush)
+static bool use_chunk(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
+{
+    return c->tap_chunked == 1 && chunk_ok(c, d, q, k);
+}
+
 static int mfma_kind(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
     if (d.in_dtype == DAAM_BF16) return 66;                   // only reached when use_d64_bf16() holds
+    if (use_chunk(c, d, q, k)) return 70;
     if (use_d64(c, d, q, k)) return 65;
     if (use_wide(c, d, q, k)) return d.head_dim <= 96 ? 67 : 69;
     return tap_mfma_ksteps(d.head_dim);
@@ -636,6 +658,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     const int kd1 = mfma ? mfma_kind(c, *d, q, k) : 0;
     hipError_t e = (kd1 == 65 || kd1 == 66) ? launch_tap_d64(L, d->in_dtype, c->acc_dtype, c->fast_exp && d->round_logits, d->head_dim == 64, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : (kd1 == 67 || kd1 == 69) ? launch_tap_wide(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+                   : kd1 == 70 ? launch_tap_chunk(L, c->acc_dtype, c->fast_exp && d->round_logits, 0, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                         : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
                                              &c->last_grid[0], &c->last_lds[0]);
@@ -792,6 +815,20 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         }
         per[i].push_back(&p);
     }
+    // A launch that mixes head dims (SD-v1.5: 40 / 80 / 160 = the head_dim-64 kernel and the two wide ones side by side, whose LDS
+    // footprints keep them from sharing CUs): every such layer on the chunked kernel instead -- ONE kind of workgroup, one launch,
+    // no side streams, bit-identical sums (tests/test_gpu_chunked.py; +11 ... 13 % heat maps / s on the SD-v1.5 workload).
+    if (c->tap_chunked == 2) {
+        bool k65 = false, k67 = false, k69 = false, all_ok = true;
+        for (size_t i = 0; i < kind.size(); ++i) {
+            if (kind[i] != 65 && kind[i] != 67 && kind[i] != 69) continue;
+            (kind[i] == 65 ? k65 : kind[i] == 67 ? k67 : k69) = true;
+            for (const Pending* p : per[i]) all_ok = all_ok && chunk_ok(c, p->d, p->q, p->k);
+        }
+        if (all_ok && (int)k65 + (int)k67 + (int)k69 >= 2)
+            for (int& kd : kind)
+                if (kd == 65 || kd == 67 || kd == 69) kd = 70;
+    }
     std::vector<int> kinds;
     for (int kd : kind)
         if (std::find(kinds.begin(), kinds.end(), kd) == kinds.end()) kinds.push_back(kd);
@@ -899,6 +936,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         int grid = 0;
         hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, ks, &grid, &c->last_lds[0])
                      : (pr.kd == 67 || pr.kd == 69) ? launch_tap_wide(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
+                     : pr.kd == 70 ? launch_tap_chunk(pr.L, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d != pr.max_d, ks, &grid, &c->last_lds[0])
                      : pr.kd ? launch_tap_mfma(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
                              : launch_tap_generic(pr.L, in_dtype, c->acc_dtype, pr.max_d, ks, &grid, &c->last_lds[0]);
         grid_total += grid;

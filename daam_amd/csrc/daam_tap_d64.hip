@@ -40,6 +40,14 @@
 #define DAAM_TAP_DMA 1
 #endif
 
+// TLB-warming touch (experiment, off by default; -DDAAM_TAP_TOUCH=N): a wave reads ONE dword of the Q rows and of the K tensor it
+// will fetch N steps later.  Why: the launch time depends on the FOOTPRINT of the recorded Q / K, not only on the bytes moved
+// (tools/exp/pool_sweep.py: 1.65-1.67 ms with 1.2-4.7 GB of distinct step sets, 1.89-1.95 ms with 9.7-19.4 GB: the reach of
+// the address translation caches); every step of a deferred launch reads another tensor, i.e. other pages.
+#ifndef DAAM_TAP_TOUCH
+#define DAAM_TAP_TOUCH 0
+#endif
+
 namespace daam {
 
 constexpr int kTapRow = 128;                        // bytes per K / Q row in LDS (head_dim 64 x fp16), chunks swizzled
@@ -49,7 +57,7 @@ constexpr int kTapQOff = 2 * kTapKBuf;              // Q tiles of the four waves
 
 template <typename ACC_T> constexpr size_t tap_d64_lds_bytes() {
     const size_t kb = 2 * (size_t)kTapKBuf + 4 * (size_t)kTapQTile, st = (size_t)kTok * kMfmaPixels * sizeof(ACC_T);
-    return (kb > st ? kb : st) + (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);     // fp16 sums: 37888 -> 4 workgroups per CU
+    return (kb > st ? kb : st) + (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*) + (DAAM_TAP_TOUCH ? 256 : 0);     // fp16 sums: 37888 -> 4 workgroups per CU
 }
 
 // byte offset of 16-byte chunk `chunk` inside row `row` of a swizzled [rows][128 B] image
@@ -63,7 +71,8 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     constexpr int KCH = (kTok * 8 + 255) / 256;               // 16-B K pieces per thread per step (3)
     constexpr int VEC = AccVec<ACC_T>::kPerVec;
     constexpr int PPR = kMfmaPixels / VEC;
-    constexpr size_t kPtrOff = tap_d64_lds_bytes<ACC_T>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);
+    constexpr size_t kPtrOff = tap_d64_lds_bytes<ACC_T>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*) - (DAAM_TAP_TOUCH ? 256 : 0);
+    constexpr size_t kTouchOff = tap_d64_lds_bytes<ACC_T>() - 256;     // DAAM_TAP_TOUCH: 256 bytes nobody reads
 
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* kbuf = smem;                               // [2][kTapKBuf], then the four waves' Q tiles
@@ -261,11 +270,19 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(qtile + i * 1024), 16, qd_src[i & 1], q_s[i], 0, DAAM_TAP_Q_AUX);
     };
 #endif
+#if DAAM_TAP_TOUCH
+    const unsigned q_touch = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)((q_off + (int64_t)min(p0 + wave * 32, lay.hw - 1) * lay.q_sp) * 2));
+#endif
     // one denoising step: logits of step s from the K and Q tiles in LDS, then the fetches of the next step (head_dim 64: by DMA
     // into the other K buffer / this wave's own Q tile, whose reads are behind it; head_dim < 64: step s + 1 from the staging
     // registers into LDS and the request for step s + 2), softmax + accumulate of the two pixel groups
     auto step = [&](int s) {
-#if !defined(DAAM_TAP_ABLATE) || DAAM_TAP_ABLATE != 1         // timing experiment 1: no per-step barrier (results are wrong)
+#if DAAM_TAP_TOUCH
+        // bare barrier: __syncthreads() carries a fence, for which hipcc waits vmcnt(0) -- the touches would be waited for after all.
+        // LDS visibility: this wave's DMAs were waited for at the end of the previous step, its LDS reads were consumed by the MFMAs
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#elif !defined(DAAM_TAP_ABLATE) || DAAM_TAP_ABLATE != 1       // timing experiment 1: no per-step barrier (results are wrong)
         __syncthreads();
 #endif
         const unsigned char* kb = kbuf + (s & 1) * kTapKBuf;
@@ -288,6 +305,15 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             // tile was read by the operand loads above, which the MFMAs have consumed
             dma_k(min(s + 1, n_steps - 1), (s + 1) & 1);
             dma_q(min(s + 1, n_steps - 1));
+#if DAAM_TAP_TOUCH
+            {
+                // one dword of the Q rows / the K tensor this wave fetches DAAM_TAP_TOUCH steps later, by DMA into a scratch corner
+                // of LDS (never read): no destination registers, so nothing waits for them but the counted waits below
+                const int st = min(s + DAAM_TAP_TOUCH, n_steps - 1);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(tensor(sptr[2 * st]), (lds_ptr_t)(smem + kTouchOff), 4, 0, q_touch, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(tensor(sptr[2 * st + 1]), (lds_ptr_t)(smem + kTouchOff), 4, 0, k_base, 0, 0);
+            }
+#endif
         } else {
             // head_dim < 64 (register-staged): the pieces of step s + 1 were requested a whole step ago -- into LDS now (K buffer
             // (s + 1) & 1 was last read in step s - 1, which every wave left before this step's barrier; the Q tile is this wave's
@@ -314,7 +340,11 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         }
 #if DAAM_TAP_DMA
         if constexpr (FULL64) {
+#if DAAM_TAP_TOUCH
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // the DMAs have landed; the two touches (issued last) may still be in flight
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs have landed; the next step's barrier publishes K
+#endif
         }
 #else
         commit_k((s + 1) & 1);

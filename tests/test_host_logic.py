@@ -694,3 +694,36 @@ def test_generated_finalize_schedule_is_current(tmp_path):
         for kind in ('prefill', 'asm'):
             name = f'daam_finalize_pipe_{kind}_r{ring}.inc'
             assert open(os.path.join(str(tmp_path), name)).read() == open(os.path.join(ROOT, 'daam_amd', 'csrc', name)).read(), name
+
+
+@pytest.mark.parametrize('head_dim,hw,p0', [(8, 64, 0), (40, 256, 128), (64, 128, 0), (80, 256, 0), (120, 64, 0), (160, 256, 128),
+                                            (256, 128, 0), (160, 200, 128)])
+def test_tap_chunk_data_path_model(head_dim, hw, p0):
+    """The index arithmetic of tap_chunk_kernel (LDS-DMA sources with the swizzle on the source side, clamped rows, partial last
+    chunk, Q-operand masks, k-step skip), modelled lane by lane on the host (tools/emulate_tap_chunk.py), reproduces q . k for
+    every (pixel, token) of a workgroup tile of the LAST head of the last batch (NaN guard halves behind the tensors: a piece
+    past head_dim that was not clamped would show up), and the padded slots stay finite."""
+    from tools import emulate_tap_chunk as em
+    err, finite = em.check(head_dim, hw, p0=p0, verbose=False)
+    assert err < 2e-3 and finite
+
+
+def test_committed_counters_match_this_build_kernel_by_kernel():
+    """profiles/r03_counters.json carries the machine-code fingerprint of every kernel of the build it was measured on; bench.py
+    takes its numbers only while each of them is byte-identical in the library built from this tree (source files added since,
+    or compiled-out experiments, change ``csrc_sha`` but not the measured kernels)."""
+    import bench
+    from daam_amd import build
+    build.build(verbose=False)
+    have = build.kernel_shas()
+    assert len(have) > 100 and all(len(v) == 12 for v in have.values())
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r03_counters.json')))
+    changed = [k for k, v in rec['kernel_shas'].items() if have.get(k) != v]
+    assert not changed, changed
+    prof, note = bench.load_counters()
+    assert prof is not None and 'r03_counters.json' in note
+    # a kernel that differs invalidates the file
+    want = dict(rec['kernel_shas'])
+    first = next(iter(want))
+    want[first] = '0' * 12
+    assert [k for k, v in want.items() if have.get(k) != v] == [first]
