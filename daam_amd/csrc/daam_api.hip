@@ -30,7 +30,7 @@ bool tap_d64_supported(int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t
                        const void* q, const void* k);
 bool tap_chunk_supported(int in_dtype, int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                          int64_t q_extent, const void* q, const void* k);
-hipError_t launch_tap_chunk(const TapLaunch&, int acc_dtype, int fast_exp, int interleave, hipStream_t, int*, int*);
+hipError_t launch_tap_chunk(const TapLaunch&, int in_dtype, int acc_dtype, int fast_exp, int interleave, hipStream_t, int*, int*);
 
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
@@ -576,12 +576,13 @@ static void fill_layer(const DaamCtx* c, const Layer& l, const DaamQKDesc& d, in
 }
 
 static bool use_d64_bf16(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k);
+static bool use_chunk(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k);
 
 static bool use_mfma(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
     if (c->force_generic) return false;
     if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) return false;
-    if (d.in_dtype == DAAM_BF16) return use_d64_bf16(c, d, q, k);
+    if (d.in_dtype == DAAM_BF16) return use_d64_bf16(c, d, q, k) || use_chunk(c, d, q, k);
     return tap_mfma_supported(d.in_dtype, d.head_dim, d.tokens, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b,
                               d.q_stride_h, d.k_stride_b, d.k_stride_h);
 }
@@ -614,11 +615,18 @@ static bool use_wide(const DaamCtx* c, const DaamQKDesc& d, const void* q, const
                               d.k_stride_h, q, k);
 }
 
-// the chunked kernel (daam_tap_chunk.hip) takes this call: fp16 layers of any head_dim (multiple of 8, <= 256)
+// the chunked kernel (daam_tap_chunk.hip) takes this call: fp16 layers of any head_dim (multiple of 8, <= 256); bf16 layers too (bf16
+// or f32 sums, bf16-rounded logits, the fast softmax -- what the bf16 head_dim-64 kernel asks for), but those only with DAAM_TAP_CHUNKED=1:
+// that instantiation has not run on the chip yet (round 3 ended without GPU time), a bf16 head_dim > 64 layer stays on the any-shape kernel
 static bool chunk_ok(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
-    return c->tap_chunked && !c->no_d64 && (c->acc_dtype == DAAM_F16 || c->acc_dtype == DAAM_F32) && d.tokens == 77 &&
-           tap_chunk_supported(d.in_dtype, d.head_dim, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h, d.k_stride_b,
+    if (!c->tap_chunked || c->no_d64 || c->force_generic || d.tokens != 77) return false;
+    if (d.in_dtype == DAAM_BF16) {
+        if (c->tap_chunked != 1 || !c->fast_exp || !d.round_logits || !(c->acc_dtype == DAAM_BF16 || c->acc_dtype == DAAM_F32)) return false;
+    } else if (!(c->acc_dtype == DAAM_F16 || c->acc_dtype == DAAM_F32)) {
+        return false;
+    }
+    return tap_chunk_supported(d.in_dtype, d.head_dim, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h, d.k_stride_b,
                                d.k_stride_h, (int64_t)d.batch * d.q_stride_b, q, k);
 }
 
@@ -630,8 +638,8 @@ static bool use_chunk(const DaamCtx* c, const DaamQKDesc& d, const void* q, cons
 
 static int mfma_kind(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
-    if (d.in_dtype == DAAM_BF16) return 66;                   // only reached when use_d64_bf16() holds
     if (use_chunk(c, d, q, k)) return 70;
+    if (d.in_dtype == DAAM_BF16) return 66;                   // only reached when use_d64_bf16() holds
     if (use_d64(c, d, q, k)) return 65;
     if (use_wide(c, d, q, k)) return d.head_dim <= 96 ? 67 : 69;
     return tap_mfma_ksteps(d.head_dim);
@@ -658,7 +666,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     const int kd1 = mfma ? mfma_kind(c, *d, q, k) : 0;
     hipError_t e = (kd1 == 65 || kd1 == 66) ? launch_tap_d64(L, d->in_dtype, c->acc_dtype, c->fast_exp && d->round_logits, d->head_dim == 64, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : (kd1 == 67 || kd1 == 69) ? launch_tap_wide(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
-                   : kd1 == 70 ? launch_tap_chunk(L, c->acc_dtype, c->fast_exp && d->round_logits, 0, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+                   : kd1 == 70 ? launch_tap_chunk(L, d->in_dtype, c->acc_dtype, c->fast_exp && d->round_logits, 0, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                         : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
                                              &c->last_grid[0], &c->last_lds[0]);
@@ -936,7 +944,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         int grid = 0;
         hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, ks, &grid, &c->last_lds[0])
                      : (pr.kd == 67 || pr.kd == 69) ? launch_tap_wide(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
-                     : pr.kd == 70 ? launch_tap_chunk(pr.L, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d != pr.max_d, ks, &grid, &c->last_lds[0])
+                     : pr.kd == 70 ? launch_tap_chunk(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d != pr.max_d, ks, &grid, &c->last_lds[0])
                      : pr.kd ? launch_tap_mfma(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
                              : launch_tap_generic(pr.L, in_dtype, c->acc_dtype, pr.max_d, ks, &grid, &c->last_lds[0]);
         grid_total += grid;

@@ -1,4 +1,4 @@
-// fp16 tap for ANY head_dim that is a multiple of 8 up to 256, in the LDS / register footprint of the head_dim-64 kernel
+// fp16 (and, opt-in, bf16) tap for ANY head_dim that is a multiple of 8 up to 256, in the LDS / register footprint of the head_dim-64 kernel
 // (daam_tap_d64.hip): the contraction is walked in CHUNKS of 64 elements.  gfx950, v_mfma_f32_16x16x32_f16.
 //
 // Why (SD-v1.5, BASELINE.json configs[1]): its layers have head_dim 40 / 80 / 160, and a flush ran as three kernels side by
@@ -40,7 +40,7 @@ __device__ __forceinline__ constexpr int ck_swz(int row, int chunk) { return ((c
 // last and holds only `vc` (1..7) valid 16-byte pieces.  All conditions but the lane-quarter compares are wave-uniform.
 // (`partial` as a second template parameter -- full chunks without the selects -- costs registers: 128 VGPRs + 160 bytes of
 // scratch against 125 and none; hipcc turns the two `if`s below into eight v_cndmask each either way.)
-template <bool FIRST>
+template <typename IN, bool FIRST>
 __device__ __forceinline__ void chunk_mfma(const unsigned char* kb, const unsigned char* qtile, int f_rd, bool partial, int vc, int h,
                                            floatx4 (&c0)[5], floatx4 (&c1)[5])
 {
@@ -52,11 +52,11 @@ __device__ __forceinline__ void chunk_mfma(const unsigned char* kb, const unsign
     for (int mt = 0; mt < 5; ++mt) {
         const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kCkRow + f_rd);
         if constexpr (FIRST) {
-            c0[mt] = InF16::mfma(a0, q00, floatx4{0, 0, 0, 0});
-            c1[mt] = InF16::mfma(a0, q10, floatx4{0, 0, 0, 0});
+            c0[mt] = IN::mfma(a0, q00, floatx4{0, 0, 0, 0});
+            c1[mt] = IN::mfma(a0, q10, floatx4{0, 0, 0, 0});
         } else {
-            c0[mt] = InF16::mfma(a0, q00, c0[mt]);
-            c1[mt] = InF16::mfma(a0, q10, c1[mt]);
+            c0[mt] = IN::mfma(a0, q00, c0[mt]);
+            c1[mt] = IN::mfma(a0, q10, c1[mt]);
         }
     }
     if (!partial || vc > 4) {                                              // k-step 1 = pieces 4..7: piece 4 + h
@@ -66,14 +66,16 @@ __device__ __forceinline__ void chunk_mfma(const unsigned char* kb, const unsign
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
             const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kCkRow + (f_rd ^ 64));
-            c0[mt] = InF16::mfma(a1, q01, c0[mt]);
-            c1[mt] = InF16::mfma(a1, q11, c1[mt]);
+            c0[mt] = IN::mfma(a1, q01, c0[mt]);
+            c1[mt] = IN::mfma(a1, q11, c1[mt]);
         }
     }
 }
 
-template <typename ACC_T, bool FAST_EXP>
-__global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_chunk_kernel(const TapLaunch L)
+// IN = InF16 / InBF16 (daam_tap16_softmax.h: the MFMA and the softmax rounding points of the pipeline dtype; bf16 has one softmax
+// flavour and keeps its values in f32 registers: 3 waves per SIMD)
+template <typename IN, typename ACC_T, bool FAST_EXP>
+__global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) void tap_chunk_kernel(const TapLaunch L)
 {
     constexpr int VEC = AccVec<ACC_T>::kPerVec;
     constexpr int PPR = kMfmaPixels / VEC;
@@ -231,18 +233,23 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_chunk_k
         const int s_next = min(s + 1, n_steps - 1);           // branch-free: the last step re-fetches itself
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        chunk_mfma<true>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && n_ch == 1, vc, h, c0, c1);
+        chunk_mfma<IN, true>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && n_ch == 1, vc, h, c0, c1);
         buf ^= 1;
         if (n_ch > 1) dma(s, 1, buf); else dma(s_next, 0, buf);
         for (int c = 1; c < n_ch; ++c) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            chunk_mfma<false>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && c == n_ch - 1, vc, h, c0, c1);
+            chunk_mfma<IN, false>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && c == n_ch - 1, vc, h, c0, c1);
             buf ^= 1;
             if (c + 1 < n_ch) dma(s, c + 1, buf); else dma(s_next, 0, buf);
         }
-        softmax20_accumulate<ACC_T, FAST_EXP>(c0, lay, h, run0);
-        softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
+        if constexpr (IN::kBf16) {
+            softmax20_accumulate_bf16<ACC_T>(c0, lay, h, run0);
+            softmax20_accumulate_bf16<ACC_T>(c1, lay, h, run1);
+        } else {
+            softmax20_accumulate<ACC_T, FAST_EXP>(c0, lay, h, run0);
+            softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last (redundant) fetch has landed before the staging tile reuses the space
     __syncthreads();                                          // all K reads done
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(256, (sizeof(ACC_T) == 2 ? 4 : 3)) void tap_chunk_k
 bool tap_chunk_supported(int in_dtype, int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb,
                          int64_t k_sh, int64_t q_extent, const void* q, const void* k)
 {
-    if (in_dtype != 0 || head_dim < 8 || head_dim > kCkMaxHeadDim || head_dim % 8 != 0 || hw % 8 != 0) return false;
+    if ((in_dtype != 0 && in_dtype != 2) || head_dim < 8 || head_dim > kCkMaxHeadDim || head_dim % 8 != 0 || hw % 8 != 0) return false;
     const int64_t s[] = {q_sp, k_st, q_sb, q_sh, k_sb, k_sh};
     for (int64_t v : s)
         if (v % 8 != 0 || v < 0) return false;
@@ -277,22 +284,24 @@ bool tap_chunk_supported(int in_dtype, int head_dim, int hw, int64_t q_sp, int64
     return ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
 }
 
-template <typename ACC_T, bool FAST>
+template <typename IN, typename ACC_T, bool FAST>
 static hipError_t launch_chunk_k(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out)
 {
     const size_t lds = tap_chunk_lds_bytes<ACC_T>();
     *lds_out = lds;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_chunk_kernel<ACC_T, FAST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_chunk_kernel<IN, ACC_T, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((tap_chunk_kernel<ACC_T, FAST>), dim3(grid), dim3(256), lds, stream, L);
+    hipLaunchKernelGGL((tap_chunk_kernel<IN, ACC_T, FAST>), dim3(grid), dim3(256), lds, stream, L);
     return hipGetLastError();
 }
 
-// interleave: the launch mixes head dims (see the block mapping at the top of the kernel)
-hipError_t launch_tap_chunk(const TapLaunch& L0, int acc_dtype, int fast_exp, int interleave, hipStream_t stream, int* grid_out, int* lds_out)
+// interleave: the launch mixes head dims (see the block mapping at the top of the kernel).  in_dtype / acc_dtype: 0 = fp16, 1 = f32
+// (sums only), 2 = bf16 (bf16 pipelines: bf16 or f32 sums, the one bf16 softmax flavour).
+hipError_t launch_tap_chunk(const TapLaunch& L0, int in_dtype, int acc_dtype, int fast_exp, int interleave, hipStream_t stream, int* grid_out,
+                            int* lds_out)
 {
     TapLaunch L = L0;
     const int per = (L.total_wgs + 7) / 8;
@@ -301,9 +310,19 @@ hipError_t launch_tap_chunk(const TapLaunch& L0, int acc_dtype, int fast_exp, in
     *grid_out = grid;
     size_t lds = 0;
     hipError_t e;
-    if (acc_dtype == 0) e = fast_exp ? launch_chunk_k<_Float16, true>(L, stream, grid, &lds) : launch_chunk_k<_Float16, false>(L, stream, grid, &lds);
-    else if (acc_dtype == 1) e = fast_exp ? launch_chunk_k<float, true>(L, stream, grid, &lds) : launch_chunk_k<float, false>(L, stream, grid, &lds);
-    else return hipErrorInvalidValue;
+    if (in_dtype == 2) {
+        if (acc_dtype == 2) e = launch_chunk_k<InBF16, bf16_t, true>(L, stream, grid, &lds);
+        else if (acc_dtype == 1) e = launch_chunk_k<InBF16, float, true>(L, stream, grid, &lds);
+        else return hipErrorInvalidValue;
+    } else if (in_dtype != 0) {
+        return hipErrorInvalidValue;
+    } else if (acc_dtype == 0) {
+        e = fast_exp ? launch_chunk_k<InF16, _Float16, true>(L, stream, grid, &lds) : launch_chunk_k<InF16, _Float16, false>(L, stream, grid, &lds);
+    } else if (acc_dtype == 1) {
+        e = fast_exp ? launch_chunk_k<InF16, float, true>(L, stream, grid, &lds) : launch_chunk_k<InF16, float, false>(L, stream, grid, &lds);
+    } else {
+        return hipErrorInvalidValue;
+    }
     *lds_out = (int)lds;
     return e;
 }
