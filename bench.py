@@ -81,14 +81,30 @@ def topology(kind, latent):
     return down + up
 
 
-def make_inputs(layers, pool, device, seed):
+def make_inputs(layers, pool, device, seed, arena=False):
+    """``arena``: every Q / K of the pool is a view of ONE allocation (an experiment on what the launch time owes to how the
+    recorded tensors are spread over allocator segments -- tools/exp/pool_sweep.py; never the default: a pipeline's Q / K come
+    from the caching allocator one tensor at a time)."""
     g = torch.Generator(device=device).manual_seed(seed)
+    big, pos = None, 0
+    if arena:
+        per_set = sum(2 * side * side * heads * d + 2 * 77 * heads * d for _, heads, side, d in layers)
+        big = torch.empty(pool * per_set, device=device, dtype=torch.float16)
+
+    def new(shape):
+        nonlocal pos
+        if big is None:
+            return torch.randn(*shape, generator=g, device=device, dtype=torch.float16)
+        n = shape[0] * shape[1] * shape[2]
+        t = big[pos:pos + n].view(*shape)
+        pos += n
+        return t.normal_(generator=g)
     sets = []
     for _ in range(pool):
         cur = []
         for (_, heads, side, d) in layers:
-            q = torch.randn(2, side * side, heads * d, generator=g, device=device, dtype=torch.float16)
-            k = torch.randn(2, 77, heads * d, generator=g, device=device, dtype=torch.float16)
+            q = new((2, side * side, heads * d))
+            k = new((2, 77, heads * d))
             k[:, 0, :] *= 3.0                  # SOS-dominant keys, like real prompts (SURVEY.md 8d, d2)
             cur.append((q, k))
         sets.append(cur)
@@ -455,7 +471,7 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     layers = topology(wl['kind'], wl['latent'])
     latent_side = 64
     pool = args.pool if args.pool > 0 else min(denoise_steps, wl.get('pool_cap', denoise_steps))
-    sets = make_inputs(layers, pool, device, seed=1234 + rank)
+    sets = make_inputs(layers, pool, device, seed=1234 + rank, arena=getattr(args, 'arena', False))
     defer_bytes = args.defer_bytes if args.defer_bytes > 0 else default_defer_bytes(device)
     eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=args.accumulate, defer_steps=args.defer,
                         defer_bytes=defer_bytes)
@@ -646,6 +662,8 @@ def main():
     ap.add_argument('--pool', type=int, default=0,
                     help='distinct synthetic Q/K step sets resident in HBM (0 = one per denoising step: no step of a '
                          'generation re-reads data an earlier one left in L2 / Infinity Cache; SDXL-2048: 25 sets = 39 GB)')
+    ap.add_argument('--arena', action='store_true',
+                    help='experiment: carve every synthetic Q / K out of ONE allocation (see make_inputs); never the reported configuration')
     ap.add_argument('--no-baselines', action='store_true', help='skip the CPU / eager-GPU reference timings')
     ap.add_argument('--no-integrated', action='store_true', help='skip the integrated-overhead leg')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short legs of the other single-GPU BASELINE configurations')

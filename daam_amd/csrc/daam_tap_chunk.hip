@@ -21,6 +21,14 @@
 // registers after the LDS read (K x 0 = 0); a k-step that lies entirely past head_dim is skipped.
 #include "daam_tap16_softmax.h"
 
+// Experiment, off by default (-DDAAM_CHUNK_EARLY_DMA=1; prepared without a GPU at hand, not measured yet): the fetches of sub-step
+// u + 1 go out BEFORE the MFMAs of sub-step u instead of behind them -- the other K buffer is free once the barrier is passed, the
+// wave's own Q tile once its four operand reads have returned.  For the sub-steps of a wide head that have no softmax behind them
+// the DMA wait is fully exposed; this takes the MFMA phase off it.
+#ifndef DAAM_CHUNK_EARLY_DMA
+#define DAAM_CHUNK_EARLY_DMA 0
+#endif
+
 namespace daam {
 
 constexpr int kCkRow = 128;                         // bytes per K / Q row in LDS: one 64-element chunk, 16-byte pieces swizzled
@@ -63,6 +71,46 @@ __device__ __forceinline__ void chunk_mfma(const unsigned char* kb, const unsign
         half8 q01 = *reinterpret_cast<const half8*>(qtile + (f_rd ^ 64));
         half8 q11 = *reinterpret_cast<const half8*>(qtile + 16 * kCkRow + (f_rd ^ 64));
         if (partial && 4 + h >= vc) { q01 = zero; q11 = zero; }
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+            const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kCkRow + (f_rd ^ 64));
+            c0[mt] = IN::mfma(a1, q01, c0[mt]);
+            c1[mt] = IN::mfma(a1, q11, c1[mt]);
+        }
+    }
+}
+
+// DAAM_CHUNK_EARLY_DMA: the same MFMAs with the Q operands read up front and `issue` (the next sub-step's DMAs) called between the
+// operand reads and the MFMAs
+template <typename IN, bool FIRST, typename F>
+__device__ __forceinline__ void chunk_mfma_early(const unsigned char* kb, const unsigned char* qtile, int f_rd, bool partial, int vc, int h,
+                                                 floatx4 (&c0)[5], floatx4 (&c1)[5], F&& issue)
+{
+    const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool two = !partial || vc > 4;                                   // wave-uniform
+    half8 q00 = *reinterpret_cast<const half8*>(qtile + f_rd);
+    half8 q10 = *reinterpret_cast<const half8*>(qtile + 16 * kCkRow + f_rd);
+    half8 q01 = zero, q11 = zero;
+    if (two) {
+        q01 = *reinterpret_cast<const half8*>(qtile + (f_rd ^ 64));
+        q11 = *reinterpret_cast<const half8*>(qtile + 16 * kCkRow + (f_rd ^ 64));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // the tile's reads have returned: it may be overwritten
+    issue();
+    if (partial && vc < 4 && h >= vc) { q00 = zero; q10 = zero; }
+    if (partial && 4 + h >= vc) { q01 = zero; q11 = zero; }
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) {
+        const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kCkRow + f_rd);
+        if constexpr (FIRST) {
+            c0[mt] = IN::mfma(a0, q00, floatx4{0, 0, 0, 0});
+            c1[mt] = IN::mfma(a0, q10, floatx4{0, 0, 0, 0});
+        } else {
+            c0[mt] = IN::mfma(a0, q00, c0[mt]);
+            c1[mt] = IN::mfma(a0, q10, c1[mt]);
+        }
+    }
+    if (two) {
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
             const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kCkRow + (f_rd ^ 64));
@@ -233,6 +281,18 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         const int s_next = min(s + 1, n_steps - 1);           // branch-free: the last step re-fetches itself
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#if DAAM_CHUNK_EARLY_DMA
+        chunk_mfma_early<IN, true>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && n_ch == 1, vc, h, c0, c1,
+                                   [&] { if (n_ch > 1) dma(s, 1, buf ^ 1); else dma(s_next, 0, buf ^ 1); });
+        buf ^= 1;
+        for (int c = 1; c < n_ch; ++c) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            chunk_mfma_early<IN, false>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && c == n_ch - 1, vc, h, c0, c1,
+                                        [&] { if (c + 1 < n_ch) dma(s, c + 1, buf ^ 1); else dma(s_next, 0, buf ^ 1); });
+            buf ^= 1;
+        }
+#else
         chunk_mfma<IN, true>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && n_ch == 1, vc, h, c0, c1);
         buf ^= 1;
         if (n_ch > 1) dma(s, 1, buf); else dma(s_next, 0, buf);
@@ -243,6 +303,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             buf ^= 1;
             if (c + 1 < n_ch) dma(s, c + 1, buf); else dma(s_next, 0, buf);
         }
+#endif
         if constexpr (IN::kBf16) {
             softmax20_accumulate_bf16<ACC_T>(c0, lay, h, run0);
             softmax20_accumulate_bf16<ACC_T>(c1, lay, h, run1);
