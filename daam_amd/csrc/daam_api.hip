@@ -827,15 +827,21 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     // footprints keep them from sharing CUs): every such layer on the chunked kernel instead -- ONE kind of workgroup, one launch,
     // no side streams, bit-identical sums (tests/test_gpu_chunked.py; +11 ... 13 % heat maps / s on the SD-v1.5 workload).
     if (c->tap_chunked == 2) {
-        bool k65 = false, k67 = false, k69 = false, all_ok = true;
-        for (size_t i = 0; i < kind.size(); ++i) {
-            if (kind[i] != 65 && kind[i] != 67 && kind[i] != 69) continue;
-            (kind[i] == 65 ? k65 : kind[i] == 67 ? k67 : k69) = true;
-            for (const Pending* p : per[i]) all_ok = all_ok && chunk_ok(c, p->d, p->q, p->k);
+        bool k65 = false, k67 = false, k69 = false;
+        for (int kd : kind) {
+            k65 = k65 || kd == 65;
+            k67 = k67 || kd == 67;
+            k69 = k69 || kd == 69;
         }
-        if (all_ok && (int)k65 + (int)k67 + (int)k69 >= 2)
-            for (int& kd : kind)
-                if (kd == 65 || kd == 67 || kd == 69) kd = 70;
+        if ((int)k65 + (int)k67 + (int)k69 >= 2) {            // (an SDXL launch -- one kind -- never gets here: no per-call checks)
+            bool all_ok = true;
+            for (size_t i = 0; i < kind.size() && all_ok; ++i)
+                if (kind[i] == 65 || kind[i] == 67 || kind[i] == 69)
+                    for (const Pending* p : per[i]) all_ok = all_ok && chunk_ok(c, p->d, p->q, p->k);
+            if (all_ok)
+                for (int& kd : kind)
+                    if (kd == 65 || kd == 67 || kd == 69) kd = 70;
+        }
     }
     std::vector<int> kinds;
     for (int kd : kind)
