@@ -26,7 +26,7 @@ def find(d, suffix):
 def short(name):
     if 'daam' not in name:
         return None
-    for k in ('tap_d64_kernel', 'tap_wide_kernel', 'tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'attend_kernel', 'finalize_up32_pipe_kernel',
+    for k in ('tap_d64_kernel', 'tap_chunk_kernel', 'tap_wide_kernel', 'tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'attend_kernel', 'finalize_up32_pipe_kernel',
               'finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_down2_kernel',
               'finalize_up_kernel', 'finalize_same_kernel', 'finalize_kernel', 'normalize_kernel', 'word_'):
         if k in name:
@@ -72,7 +72,7 @@ def main():
         tpath = os.path.join(a.out, 'hbm_traffic.json')
         traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
         rec = {}
-        for kern, field in (('tap_d64_kernel', 'tap'), ('tap_mfma_kernel', 'tap'), ('finalize_up32_pipe_kernel', 'finalize_pipe'),
+        for kern, field in (('tap_d64_kernel', 'tap'), ('tap_chunk_kernel', 'tap'), ('tap_mfma_kernel', 'tap'), ('finalize_up32_pipe_kernel', 'finalize_pipe'),
                             ('finalize_up32_same_kernel', 'finalize_pair'), ('finalize_up32_mfma_kernel', 'finalize_up'),
                             ('finalize_same_kernel', 'finalize_same')):
             cs = pmc.get(kern, {})
@@ -93,11 +93,13 @@ def main():
         # what bench.py reads for its rooflines (profiles/<tag>_counters.json), tied to the kernel sources by their fingerprint
         import sys
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        from daam_amd.build import csrc_sha
+        from daam_amd.build import csrc_sha, kernel_shas
         cpath = os.path.join(a.out, a.tag.split('_')[0] + '_counters.json')      # one file per round, one entry per workload
         counters = json.load(open(cpath)) if os.path.exists(cpath) else {}
         if counters.get('csrc_sha') != csrc_sha():
-            counters = dict(csrc_sha=csrc_sha(), workloads={},
+            counters = dict(csrc_sha=csrc_sha(), workloads={}, kernel_shas=dict(sorted(kernel_shas().items())),
+                            kernel_shas_note='machine-code fingerprints of every kernel of the measured build (daam_amd.build.kernel_shas): bench.py '
+                                             'accepts this file for a later build whose sources differ while all of these are byte-identical in it',
                             method='rocprofv3 --pmc passes of `python bench.py --workload W` (tools/profile_round.sh); per launch: '
                                    'upper-median over the launches of a kernel; *_per_simd = counter / 1024 SIMDs; '
                                    'VALU busy cycles = SQ_ACTIVE_INST_VALU (quad-cycles) x 4; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024')
@@ -107,8 +109,9 @@ def main():
         def upper_median(v):
             v = sorted(v)
             return statistics.median(v[len(v) // 2:])
-        tap_names = [k for k in ('tap_d64_kernel', 'tap_wide_kernel', 'tap_mfma_kernel') if k in pmc and 'SQ_ACTIVE_INST_VALU' in pmc[k]]
+        tap_names = [k for k in ('tap_d64_kernel', 'tap_chunk_kernel', 'tap_wide_kernel', 'tap_mfma_kernel') if k in pmc and 'SQ_ACTIVE_INST_VALU' in pmc[k]]
         if tap_names:
+            w['tap_kernels_per_launch'] = len(tap_names)          # bench.py drops the tap counters when the launch structure differs
             # a flush may run several tap kernels side by side (SD-v1.5): their work adds up on the same SIMDs
             w['tap_valu_busy_cycles_per_simd'] = round(sum(upper_median(pmc[k]['SQ_ACTIVE_INST_VALU']) for k in tap_names) * 4 / 1024, 1)
             w['tap_valu_insts_per_simd'] = round(sum(upper_median(pmc[k]['SQ_INSTS_VALU']) for k in tap_names) / 1024, 1)
