@@ -728,3 +728,27 @@ def test_committed_counters_are_tied_to_the_build_kernel_by_kernel():
         assert prof is not None and 'r03_counters.json' in note
     # the fingerprint is of the code, not of the name: two different kernels never share one
     assert len(set(have.values())) == len(have)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/daam_hip.h compiles as C99 (-pedantic), and a C program -- the shape of the cgo / JNI
+    / ctypes stub INTEGRATION.md shows -- links against libdaam_hip.so and calls the entry points that need no GPU."""
+    import subprocess
+    from daam_amd import _native, build
+    build.build(verbose=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / 'abi.c'
+    src.write_text('#include <stdio.h>\n#include "daam_hip.h"\n'
+                   'int main(void) {\n'
+                   '    DaamCtx* ctx = 0;\n'
+                   '    int v = daam_abi_version();\n'
+                   '    int rc = daam_ctx_create(4, 99, 64, 0, &ctx);      /* tokens > 80: refused before any device call */\n'
+                   '    printf("%d %d %s\\n", v, rc, daam_last_error());\n'
+                   '    return (rc != 0 && ctx == 0) ? 0 : 1;\n'
+                   '}\n')
+    exe = tmp_path / 'abi'
+    libdir = os.path.dirname(_native.LIB_PATH)
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I' + os.path.join(root, 'include'), str(src), '-o', str(exe),
+                    '-L' + libdir, '-l:' + os.path.basename(_native.LIB_PATH), '-Wl,-rpath,' + libdir], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split(None, 2)
+    assert int(out[0]) == _native.ABI_VERSION and int(out[1]) == -1 and 'tokens' in out[2]
