@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     constexpr int VEC = AccVec<ACC_T>::kPerVec;
     constexpr int PPR = kMfmaPixels / VEC;
     constexpr size_t kPtrOff = tap_d64_lds_bytes<ACC_T>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*) - (DAAM_TAP_TOUCH ? 256 : 0);
-    constexpr size_t kTouchOff = tap_d64_lds_bytes<ACC_T>() - 256;     // DAAM_TAP_TOUCH: 256 bytes nobody reads
+    [[maybe_unused]] constexpr size_t kTouchOff = tap_d64_lds_bytes<ACC_T>() - 256;     // DAAM_TAP_TOUCH: 256 bytes nobody reads
 
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* kbuf = smem;                               // [2][kTapKBuf], then the four waves' Q tiles
