@@ -183,7 +183,7 @@ def test_full_size_parity_with_reference_processor(sdxl_stack):
     """The headline configuration (SDXL-1024, head_dim 64, H = 10 / 20, fp16 sums, 1100 keys) compared NUMERICALLY:
     same steps, same inputs, traced path against the reference-style processor + port of compute_global_heat_map."""
     pipe = sdxl_stack
-    steps = 20
+    steps = 50                                                   # the configuration's own length (BASELINE.json configs[2])
     prompt = 'a photo of a monkey riding a bicycle'
     sample = list(range(0, 1100, 37)) + [1099]
     got = _traced_generation(pipe, prompt, steps, sample)
