@@ -403,7 +403,7 @@ def load_profile(name):
     return None, f'profiles/{name} was measured on kernel sources {rec.get("csrc_sha")}, this build is {csrc_sha()}'
 
 
-COUNTER_FILES = ('r03_counters.json', 'r02_counters.json')      # newest first; only one matching this build is used
+COUNTER_FILES = ('r04_counters.json', 'r03_counters.json', 'r02_counters.json')      # newest first; only one matching this build is used
 
 
 def load_counters():
@@ -414,6 +414,94 @@ def load_counters():
             return prof, n
         note = note or n
     return None, note
+
+
+_TAP_KERNELS = ('tap_d64_kernel', 'tap_chunk_kernel', 'tap_wide_kernel', 'tap_mfma_kernel', 'tap_generic_kernel')
+_FIN_KERNELS = ('finalize_up32_pipe_kernel', 'finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_down2_kernel',
+                'finalize_up_kernel', 'finalize_same_kernel', 'finalize_kernel')
+
+
+def pmc_child(args):
+    """``--pmc-child``: what measure_traffic() runs under rocprofv3 -- a few generations of the workload, nothing else."""
+    torch.cuda.set_device(0)
+    device = torch.device('cuda', 0)
+    from daam_amd.engine import HeatMapEngine
+    wl = WORKLOADS[args.workload]
+    denoise = args.denoise_steps or wl.get('denoise_steps', 50)
+    layers = topology(wl['kind'], wl['latent'])
+    pool = args.pool if args.pool > 0 else min(denoise, wl.get('pool_cap', denoise))
+    sets = make_inputs(layers, pool, device, seed=1234)
+    eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=args.accumulate, defer_steps=args.defer,
+                        defer_bytes=args.defer_bytes if args.defer_bytes > 0 else default_defer_bytes(device))
+    calls = call_lists(layers, sets, 64)
+    for _ in range(4):
+        one_generation(eng, calls, denoise)
+    torch.cuda.synchronize()
+    eng.close()
+
+
+def measure_traffic(args, denoise, launches_per_gen, timeout_s=150):
+    """HBM bytes of the tap launch and of the finalize kernels, measured IN THIS RUN: two children of this script
+    (``--pmc-child``: four generations of the same workload) under ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` and ``--pmc
+    WRITE_SIZE`` (separate passes, no other trace domain), converted as /opt/skills/guides/MI355X_MICROARCH.md prescribes for
+    gfx950: bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024.  Per launch = upper median over the kernel's dispatches (the first
+    generation's launch compiles / warms).  Returns (dict or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    rp = shutil.which('rocprofv3')
+    if rp is None:
+        return None, 'rocprofv3 is not on PATH'
+    vals = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='daam_pmc_', dir='/tmp')
+        cmd = [rp, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__),
+               '--pmc-child', '--workload', args.workload, '--denoise-steps', str(denoise), '--defer', str(args.defer),
+               '--defer-bytes', str(args.defer_bytes), '--accumulate', args.accumulate, '--pool', str(args.pool)]
+        try:
+            res = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                 timeout=timeout_s, text=True)
+            if res.returncode != 0:
+                return None, f'rocprofv3 --pmc {counter} child failed (rc {res.returncode}): {res.stderr[-200:]}'
+            fs = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            if not fs:
+                return None, f'rocprofv3 --pmc {counter}: no counter_collection.csv'
+            for row in csv.DictReader(open(fs[0])):
+                if row['Counter_Name'] != counter:
+                    continue
+                for k in _TAP_KERNELS + _FIN_KERNELS:
+                    if k in row['Kernel_Name']:
+                        vals.setdefault(k, {}).setdefault(counter, []).append(float(row['Counter_Value']))
+                        break
+        except subprocess.TimeoutExpired:
+            return None, f'rocprofv3 --pmc {counter} child timed out after {timeout_s} s'
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    def upper_median(v):
+        v = sorted(v)
+        return statistics.median(v[len(v) // 2:])
+
+    def kernel_bytes(k):
+        cs = vals.get(k, {})
+        if 'FETCH_SIZE' not in cs or 'WRITE_SIZE' not in cs:
+            return None
+        return dict(read=int(2 * upper_median(cs['FETCH_SIZE']) * 1024), write=int(upper_median(cs['WRITE_SIZE']) * 1024),
+                    dispatches=len(cs['FETCH_SIZE']))
+    per = {k: kernel_bytes(k) for k in vals}
+    per = {k: v for k, v in per.items() if v}
+    tap = [v for k, v in per.items() if k in _TAP_KERNELS]
+    fin = [v for k, v in per.items() if k in _FIN_KERNELS]
+    if not tap:
+        return None, 'no tap kernel in the counter output'
+    return dict(tap_bytes_per_launch=sum(v['read'] + v['write'] for v in tap), finalize_bytes_per_call=sum(v['read'] + v['write'] for v in fin),
+                per_kernel=per, launches_per_generation=launches_per_gen,
+                method='two children of this run under rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); '
+                       'bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 rule of MI355X_MICROARCH.md); upper median over a kernel\'s dispatches; '
+                       'a generation of several tap launches: the figure is the typical (read-modify-write) launch'), None
 
 
 def default_defer_bytes(device):
@@ -437,6 +525,16 @@ class Comm:
         else:
             dist.init_process_group('gloo')
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def library(self):
+        """What carried the collectives, as the process group reports it (a SCALE record then shows RCCL saw N ranks)."""
+        if self.backend == 'nccl':
+            try:
+                v = torch.cuda.nccl.version()
+                return 'RCCL ' + '.'.join(str(x) for x in (v if isinstance(v, tuple) else (v,))) + f', world_size {self.dist.get_world_size()}'
+            except Exception as e:                           # noqa: BLE001 -- reporting only
+                return f'nccl (version unavailable: {e}), world_size {self.dist.get_world_size()}'
+        return f'gloo (torch {torch.__version__}), world_size {self.dist.get_world_size()}'
 
     def barrier(self):
         self.dist.barrier()
@@ -597,13 +695,18 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
         clock = mon.read()
         roofline_issue = dict(bound='issue', kernel=tap_kernel, clock=clock, ms_per_launch=round(tap_ms, 4))
         if rec and clock and rec.get('tap_valu_busy_cycles_per_simd'):
-            cyc = rec['tap_valu_busy_cycles_per_simd'] + 10.0 * rec.get('tap_mfma_per_simd', 0)
-            floor_ms = cyc / (clock['mhz_median_under_load'] * 1e3)
+            # two numbers: a FLOOR (the VALU-busy cycles the hardware counted per SIMD: nothing can run faster than its own VALU
+            # stream) and an ESTIMATE that also charges ~10 cycles of closed VALU port per MFMA (tools/gen_ubench_issue.py; an upper
+            # estimate of that block -- launches have been measured up to 4 % under it, so it is not reported as a bound)
+            mhz = clock['mhz_median_under_load'] * 1e3
+            floor_ms = rec['tap_valu_busy_cycles_per_simd'] / mhz
+            est_ms = (rec['tap_valu_busy_cycles_per_simd'] + 10.0 * rec.get('tap_mfma_per_simd', 0)) / mhz
             roofline_issue.update(valu_busy_cycles_per_simd=rec['tap_valu_busy_cycles_per_simd'],
                                   valu_insts_per_simd=rec.get('tap_valu_insts_per_simd'),
-                                  mfma_insts_per_simd=rec.get('tap_mfma_per_simd'), mfma_issue_block_cycles=10,
-                                  floor_ms=round(floor_ms, 4), frac=round(floor_ms / tap_ms, 4), source=prof_note,
-                                  counters_measured_in_run=False)
+                                  mfma_insts_per_simd=rec.get('tap_mfma_per_simd'), mfma_issue_block_cycles_estimate=10,
+                                  floor_ms=round(floor_ms, 4), frac=round(floor_ms / tap_ms, 4),
+                                  estimate_ms=round(est_ms, 4), measured_over_estimate=round(tap_ms / est_ms, 4),
+                                  measured_cycles_per_simd=int(tap_ms * mhz), source=prof_note, counters_measured_in_run=False)
         else:
             roofline_issue['note'] = prof_note or 'no PMC pass committed for this workload'
     out['roofline_issue'] = roofline_issue
@@ -622,21 +725,27 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     fin_clock = mon.read()
     fin_bytes = acc_total + 77 * 64 * 64 * 4
     fin_gbs = fin_bytes / (fin_ms * 1e-3) / 1e9
-    fin_kernel = {'sdxl1024': 'table upload + zeroing, finalize_up32_pipe_kernel (x2 class software-pipelined on the matrix cores; the same-size keys ride along)',
-                  'sdxl2048': 'table upload + zeroing, finalize_down2 (128 -> 64) + finalize_same_kernel',
-                  'sd15': 'table upload + zeroing, finalize_up32_pipe_kernel (x2 + same-size keys) + finalize_up_kernel<16>'}[name]
-    fin_issue = dict(bound='issue', kernel=fin_kernel, clock=fin_clock, ms_per_launch=round(fin_ms, 4))
+    fin_kernel = {'sdxl1024': 'finalize_up32_pipe_kernel (x2 class software-pipelined on the matrix cores; the same-size keys ride along)',
+                  'sdxl2048': 'finalize_down2 (128 -> 64) + finalize_same_kernel',
+                  'sd15': 'finalize_up32_pipe_kernel (x2 + same-size keys) + finalize_up_kernel<16>'}[name]
+    fin_kernel += ('; key tables cached on the device, output cleared by the upload kernel of the tap launch in front (daam_finalize_prepare, ABI v5): '
+                   'the timed call is the class kernel(s) only')
+    fin_issue = dict(bound='matrix-pipe / issue', kernel=fin_kernel, clock=fin_clock, ms_per_launch=round(fin_ms, 4))
     if rec and fin_clock and rec.get('finalize_valu_busy_cycles_per_simd'):
         n_mfma = rec.get('finalize_mfma_per_simd', 0)
-        cyc = max(rec['finalize_valu_busy_cycles_per_simd'] + 10.0 * n_mfma, 32.6 * n_mfma)
-        fl = cyc / (fin_clock['mhz_median_under_load'] * 1e3)
+        mhz = fin_clock['mhz_median_under_load'] * 1e3
+        pipe_ms = 32.6 * n_mfma / mhz                                  # v_mfma_f32_32x32x16_f16: 32.6 cycles of matrix pipe each (tools/ubench_mfma.hip)
+        valu_ms = rec['finalize_valu_busy_cycles_per_simd'] / mhz
+        fl = max(pipe_ms, valu_ms)
         fin_issue.update(valu_busy_cycles_per_simd=rec['finalize_valu_busy_cycles_per_simd'],
-                         mfma_insts_per_simd=n_mfma, mfma_issue_block_cycles=10, mfma_pipe_cycles_each=32.6,
-                         model='max(VALU busy + 10 cycles of closed VALU port per MFMA, MFMA count x 32.6 cycles of matrix pipe) per SIMD '
-                               '(tools/ubench_issue.hip); the class kernels only -- the timed launch also holds the table upload + zeroing kernel',
+                         mfma_insts_per_simd=n_mfma, mfma_pipe_cycles_each=32.6,
+                         model='floor = max(MFMA count x 32.6 cycles of matrix pipe, VALU-busy cycles) per SIMD at the clock sampled in this run; '
+                               'the x2 bicubic of an fp16 plane is 10 MFMA 32x32x16 per half plane (DESIGN.md 3.3): the op is bound by the matrix '
+                               'pipe, not by HBM',
+                         matrix_pipe_floor_ms=round(pipe_ms, 4), valu_floor_ms=round(valu_ms, 4),
                          floor_ms=round(fl, 4), frac=round(fl / fin_ms, 4), source=prof_note, counters_measured_in_run=False)
     out['fin_ms'] = fin_ms
-    out['roofline_finalize'] = dict(bound='hbm', kernel=fin_kernel, achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
+    out['roofline_finalize'] = dict(bound='hbm', bound_in_fact='matrix-pipe (see roofline_finalize_issue)' if name != 'sdxl2048' else 'hbm', kernel=fin_kernel, achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
                                     unit='GB/s', frac=round(fin_gbs / HBM_PEAK_GBS, 4), bytes_per_launch=int(fin_bytes),
                                     ms_per_launch=round(fin_ms, 4), traffic=rec.get('finalize_bytes_per_launch') if rec else None,
                                     traffic_measured_in_run=False)
@@ -666,6 +775,8 @@ def main():
                     help='experiment: carve every synthetic Q / K out of ONE allocation (see make_inputs); never the reported configuration')
     ap.add_argument('--no-baselines', action='store_true', help='skip the CPU / eager-GPU reference timings')
     ap.add_argument('--no-integrated', action='store_true', help='skip the integrated-overhead leg')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the in-run HBM-traffic measurement (two short children under rocprofv3 --pmc)')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short legs of the other single-GPU BASELINE configurations')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help='process-group backend of a multi-rank run: nccl = RCCL over xGMI (production); gloo = functional runs')
@@ -675,6 +786,8 @@ def main():
     args = ap.parse_args()
     if args.shared_device and args.dist_backend != 'gloo':
         raise SystemExit('--shared-device needs --dist-backend gloo (RCCL refuses a duplicate GPU)')
+    if args.pmc_child:
+        return pmc_child(args)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         _respawn_under_launcher(args.gpus, args.shared_device)
@@ -695,6 +808,17 @@ def main():
     out = None
     if rank == 0:
         r = main_rec
+        if world == 1 and not args.no_pmc:
+            note('HBM traffic: two children under rocprofv3 --pmc')
+            t, why = measure_traffic(args, denoise, r['roofline']['launches_per_generation'])
+            if t:
+                r['roofline'].update(traffic=t['tap_bytes_per_launch'], traffic_measured_in_run=True, traffic_source=t['method'],
+                                     traffic_per_kernel=t['per_kernel'],
+                                     traffic_over_algorithmic=round(t['tap_bytes_per_launch'] / r['roofline']['bytes_per_launch'], 4))
+                if t['finalize_bytes_per_call']:
+                    r['roofline_finalize'].update(traffic=t['finalize_bytes_per_call'], traffic_measured_in_run=True)
+            else:
+                r['roofline']['traffic_in_run_note'] = why
         gpu_ms_per_gen = r['tap_ms_per_generation'] + r['fin_ms']
         extra = dict(
             extraction_overhead_ms_per_denoise_step=round(r['ms_per_step'] / denoise, 4),
@@ -746,7 +870,9 @@ def main():
                        'generations_per_rank': args.steps,
                        'collective': None if world == 1 else f'all_gather of the final [{args.steps}, 77, 64, 64] fp32 maps per rank over '
                                                               f'{args.dist_backend}' + (' -- ALL RANKS ON ONE DEVICE (functional run, not a '
-                                                                                        'scaling measurement)' if args.shared_device else '')},
+                                                                                        'scaling measurement)' if args.shared_device else ''),
+                       'collective_world_size': comm.world if comm else 1,
+                       'collective_library': comm.library() if comm else None},
             'roofline': r['roofline'], 'cpu_baseline': cpu,
         }
         out.update(extra)

@@ -197,6 +197,21 @@ struct DaamCtx {
     int no_pipe_finalize = 0;         // debugging / A-B: the round-2 x2 MFMA kernel instead of the software-pipelined one
     void* d_zero_planes = nullptr;    // [tokens][32 x 32] fp16 zeros: padding keys of the pipelined x2 finalize
     int no_paired_finalize = 0;       // debugging / A-B: same-size and x2 class as two launches
+    // finalize tables kept on the device between calls: a generation's compute_global_heat_map() selects the same keys at the same
+    // addresses as the previous one, so the key / pointer tables are uploaded once and compared on the host afterwards
+    static constexpr size_t kFinTabCap = 1u << 20;
+    char* d_fin_tab = nullptr;
+    std::vector<char> fin_tab_host;   // the bytes d_fin_tab holds (when fin_tab_valid)
+    bool fin_tab_valid = false;
+    hipStream_t fin_tab_stream = nullptr;   // the stream its upload and its readers were enqueued on
+    int no_fin_cache = 0;             // debugging / A-B: DAAM_NO_FIN_CACHE=1 (tables through the ring + zeroing in every call)
+    // daam_finalize_prepare: the output buffer the next daam_finalize accumulates into has been zeroed already (prep_*), or is to
+    // be zeroed by the table-upload kernel of the next tap launch (fold_*)
+    float* prep_out = nullptr;
+    hipStream_t prep_stream = nullptr;
+    float* fold_out = nullptr;
+    size_t fold_bytes = 0;
+    hipStream_t fold_stream = nullptr;
     std::vector<Pending> pending;
     std::vector<int> pending_count;   // per layer: recorded steps
     std::vector<int> pending_last;    // per layer: index of its newest entry in `pending`
@@ -363,6 +378,7 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     hipError_t e = c->ring.init();
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_tab_idx), sizeof(int16_t) * kMaxTabs * out_side * 4);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_tab_w), sizeof(float) * kMaxTabs * out_side * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_fin_tab), DaamCtx::kFinTabCap);
     if (e != hipSuccess) {
         daam_ctx_destroy(c);
         return fail((int)e, "context allocation: %s", hipGetErrorString(e));
@@ -379,6 +395,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->no_pipe_finalize = npp && npp[0] == '1';
     const char* npf = getenv("DAAM_NO_PAIRED_FINALIZE");
     c->no_paired_finalize = npf && npf[0] == '1';
+    const char* nfc = getenv("DAAM_NO_FIN_CACHE");
+    c->no_fin_cache = nfc && nfc[0] == '1';
     const char* n16 = getenv("DAAM_NO_D64");            // debugging: 32x32-tile kernel also for head_dim 64
     c->no_d64 = n16 && n16[0] == '1';
     const char* nss = getenv("DAAM_NO_SIDE_STREAM");        // debugging / A-B: every tap kernel of a flush on the caller's stream
@@ -417,6 +435,7 @@ int daam_ctx_destroy(DaamCtx* c)
     if (c->clk_host) (void)hipHostFree(c->clk_host);
     if (c->d_up32_ops) (void)hipFree(c->d_up32_ops);
     if (c->d_zero_planes) (void)hipFree(c->d_zero_planes);
+    if (c->d_fin_tab) (void)hipFree(c->d_fin_tab);
     if (c->d_tab_idx) (void)hipFree(c->d_tab_idx);
     if (c->d_tab_w) (void)hipFree(c->d_tab_w);
     delete c;
@@ -525,6 +544,7 @@ int daam_reset(DaamCtx* c, void* stream)
 {
     if (!c) return fail(DAAM_E_INVALID, "ctx is NULL");
     c->drop_pending();
+    c->prep_out = c->fold_out = nullptr;
     (void)stream;
     for (auto& l : c->layers)
         if (l.configured) {
@@ -591,9 +611,23 @@ static bool use_mfma(const DaamCtx* c, const DaamQKDesc& d, const void* q, const
 // else the k-step count of the generic 32x32-tile MFMA kernel
 static int mfma_kind(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k);
 
+// The specialised tap kernels address Q and K with 32-bit BYTE offsets from the tensor pointers: every element a call can
+// address -- (batch - 1) * stride_b + (heads - 1) * stride_h + (rows - 1) * row stride + head_dim -- must stay below 2^30 elements
+// (views into a large fused buffer with unusual strides fall back to the any-shape kernel instead of wrapping).
+static bool offsets_fit_32(const DaamQKDesc& d)
+{
+    const int64_t lim = (int64_t)1 << 30;
+    const int64_t s[] = {d.q_stride_b, d.q_stride_h, d.q_stride_p, d.k_stride_b, d.k_stride_h, d.k_stride_t};
+    for (int64_t v : s)
+        if (v < 0 || v >= lim) return false;
+    const int64_t q_max = (int64_t)(d.batch - 1) * d.q_stride_b + (int64_t)(d.heads - 1) * d.q_stride_h + (int64_t)(d.hw - 1) * d.q_stride_p + d.head_dim;
+    const int64_t k_max = (int64_t)(d.batch - 1) * d.k_stride_b + (int64_t)(d.heads - 1) * d.k_stride_h + (int64_t)(d.tokens - 1) * d.k_stride_t + d.head_dim;
+    return q_max < lim && k_max < lim;
+}
+
 static bool use_d64(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
-    return !c->no_d64 && tap_d64_supported(d.head_dim, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h,
+    return !c->no_d64 && offsets_fit_32(d) && tap_d64_supported(d.head_dim, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h,
                                            d.k_stride_b, d.k_stride_h, q, k);
 }
 
@@ -601,7 +635,7 @@ static bool use_d64(const DaamCtx* c, const DaamQKDesc& d, const void* q, const 
 // everything else of a bf16 pipeline runs on the any-shape kernel
 static bool use_d64_bf16(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
-    return d.in_dtype == DAAM_BF16 && !c->no_d64 && c->fast_exp && d.round_logits && d.tokens == 77 && d.hw % 8 == 0 &&
+    return d.in_dtype == DAAM_BF16 && !c->no_d64 && c->fast_exp && d.round_logits && d.tokens == 77 && d.hw % 8 == 0 && offsets_fit_32(d) &&
            tap_d64_supported(d.head_dim, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h, d.k_stride_b,
                              d.k_stride_h, q, k);
 }
@@ -609,20 +643,19 @@ static bool use_d64_bf16(const DaamCtx* c, const DaamQKDesc& d, const void* q, c
 // 64 < head_dim <= 160 on fp16 pipelines (SD-v1.5's 80 / 160): the 16x16-tile kernel with 3 or 5 k-steps (daam_tap_wide.hip)
 static bool use_wide(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
-    return !c->no_d64 && (c->acc_dtype == DAAM_F16 || c->acc_dtype == DAAM_F32) &&
+    return !c->no_d64 && (c->acc_dtype == DAAM_F16 || c->acc_dtype == DAAM_F32) && offsets_fit_32(d) &&
            (int64_t)d.batch * d.q_stride_b < ((int64_t)1 << 30) &&
            tap_wide_supported(d.in_dtype, d.head_dim, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h, d.k_stride_b,
                               d.k_stride_h, q, k);
 }
 
-// the chunked kernel (daam_tap_chunk.hip) takes this call: fp16 layers of any head_dim (multiple of 8, <= 256); bf16 layers too (bf16
-// or f32 sums, bf16-rounded logits, the fast softmax -- what the bf16 head_dim-64 kernel asks for), but those only with DAAM_TAP_CHUNKED=1:
-// that instantiation has not run on the chip yet (round 3 ended without GPU time), a bf16 head_dim > 64 layer stays on the any-shape kernel
+// the chunked kernel (daam_tap_chunk.hip) can take this call: fp16 layers of any head_dim (multiple of 8, <= 256), and bf16 layers (bf16
+// or f32 sums, bf16-rounded logits, the fast softmax -- what the bf16 head_dim-64 kernel asks for; validated on the chip in round 4)
 static bool chunk_ok(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
-    if (!c->tap_chunked || c->no_d64 || c->force_generic || d.tokens != 77) return false;
+    if (!c->tap_chunked || c->no_d64 || c->force_generic || d.tokens != 77 || !offsets_fit_32(d)) return false;
     if (d.in_dtype == DAAM_BF16) {
-        if (c->tap_chunked != 1 || !c->fast_exp || !d.round_logits || !(c->acc_dtype == DAAM_BF16 || c->acc_dtype == DAAM_F32)) return false;
+        if (!c->fast_exp || !d.round_logits || !(c->acc_dtype == DAAM_BF16 || c->acc_dtype == DAAM_F32)) return false;
     } else if (!(c->acc_dtype == DAAM_F16 || c->acc_dtype == DAAM_F32)) {
         return false;
     }
@@ -630,10 +663,12 @@ static bool chunk_ok(const DaamCtx* c, const DaamQKDesc& d, const void* q, const
                                d.k_stride_h, (int64_t)d.batch * d.q_stride_b, q, k);
 }
 
-// DAAM_TAP_CHUNKED=1: every such call; by default only the deferred launches that mix head dims (daam_tap_flush)
+// DAAM_TAP_CHUNKED=1: every such call.  Default (2): the deferred launches that mix head dims (daam_tap_flush), and bf16 layers with
+// head_dim > 64 -- no other MFMA kernel has a bf16 form for them (the any-shape kernel is ~45x slower per step).
 static bool use_chunk(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
 {
-    return c->tap_chunked == 1 && chunk_ok(c, d, q, k);
+    if (c->tap_chunked == 1) return chunk_ok(c, d, q, k);
+    return c->tap_chunked == 2 && d.in_dtype == DAAM_BF16 && d.head_dim > 64 && chunk_ok(c, d, q, k);
 }
 
 static int mfma_kind(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
@@ -833,14 +868,19 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             k67 = k67 || kd == 67;
             k69 = k69 || kd == 69;
         }
-        if ((int)k65 + (int)k67 + (int)k69 >= 2) {            // (an SDXL launch -- one kind -- never gets here: no per-call checks)
+        bool k66 = false, k70 = false;                         // bf16 pipelines: head_dim <= 64 -> 66, wider heads -> 70 (use_chunk)
+        for (int kd : kind) {
+            k66 = k66 || kd == 66;
+            k70 = k70 || kd == 70;
+        }
+        if ((int)k65 + (int)k67 + (int)k69 >= 2 || (k66 && k70)) {   // (an SDXL launch -- one kind -- never gets here: no per-call checks)
             bool all_ok = true;
             for (size_t i = 0; i < kind.size() && all_ok; ++i)
-                if (kind[i] == 65 || kind[i] == 67 || kind[i] == 69)
+                if (kind[i] == 65 || kind[i] == 66 || kind[i] == 67 || kind[i] == 69)
                     for (const Pending* p : per[i]) all_ok = all_ok && chunk_ok(c, p->d, p->q, p->k);
             if (all_ok)
                 for (int& kd : kind)
-                    if (kd == 65 || kd == 67 || kd == 69) kd = 70;
+                    if (kd == 65 || kd == 66 || kd == 67 || kd == 69) kd = 70;
         }
     }
     std::vector<int> kinds;
@@ -883,8 +923,15 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             all_round = all_round && v[0]->d.round_logits;
             ++j;
         }
-        e = c->ring.commit(off, bytes, s);
+        // daam_finalize_prepare: the output of the finalize that follows this launch is cleared by this (first) upload kernel
+        const bool fold = c->fold_out && c->fold_stream == s;
+        e = c->ring.commit(off, bytes, s, fold ? c->fold_out : nullptr, fold ? c->fold_bytes : 0);
         if (e != hipSuccess) { rc = fail((int)e, "table upload: %s", hipGetErrorString(e)); break; }
+        if (fold) {
+            c->prep_out = c->fold_out;
+            c->prep_stream = s;
+            c->fold_out = nullptr;
+        }
         Prepared pr;
         pr.kd = kd;
         memset(&pr.L, 0, sizeof pr.L);
@@ -976,6 +1023,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     for (auto& v : per) c->last_flush_steps = std::max(c->last_flush_steps, (int)v.size());
     ++c->n_flushes;
     c->drop_pending();
+    c->fold_out = nullptr;                                     // one-shot: never carried to a later launch
     return rc;
 }
 
@@ -1029,20 +1077,29 @@ int daam_key_offset(DaamCtx* c, int layer, int* offset, int* total)
     return 0;
 }
 
-int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
+// ---- finalize: host-side plan (which keys, in which class, chunking of the pipelined x2 kernel) and the device tables it needs
+namespace {
+constexpr int kFinClasses = 5;       // 0 = same size (clamp + mean), 1 = x2 (32 -> 64), 2 = x4 (16 -> 64), 3 = general kernel, 4 = x0.5 (128 -> 64)
+struct FinPlan {
+    std::vector<FinKey> keys[kFinClasses];
+    int total = 0, max_side = 0;
+    bool mfma_up = false, pipe_up = false, fold_same = false;
+    int pipe_chunks = 0, pipe_nk = 0, pipe_stride = 0, same_per = 0;
+    size_t key_bytes = 0, ptr_bytes = 0;
+    std::vector<char> tab;           // FinKey array (class order) | pointer table of the pipelined x2 kernel | folded same-size pointers
+};
+int fin_env(const char* name)
 {
-    if (!c || !out) return fail(DAAM_E_INVALID, "NULL argument");
-    if (!c->pending.empty()) return fail(DAAM_E_STATE, "finalize with deferred taps pending: flush first");
-    DeviceGuard on_device(c);
-    for (auto& l : c->layers)
-        if (l.configured) {
-            int zrc = ensure_zeroed(l, (hipStream_t)stream);
-            if (zrc) return zrc;
-        }
-    // classes: 0 = same size (clamp + mean), 1 = x2 (32 -> 64), 2 = x4 (16 -> 64), 3 = general kernel, 4 = x0.5 (128 -> 64)
-    constexpr int kClasses = 5;
-    std::vector<FinKey> keys[kClasses];
-    int pos = 0, max_side = 0, total = 0;
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+}  // namespace
+
+static int fin_plan(DaamCtx* c, const uint8_t* key_mask, FinPlan& P)
+{
+    static const int env_chunks = fin_env("DAAM_FIN_CHUNKS"), env_pipe_chunks = fin_env("DAAM_FIN_PIPE_CHUNKS");   // pipelined x2 kernel only (A/B)
+    auto& keys = P.keys;
+    int pos = 0;
     for (int i = 0; i < c->max_layers; ++i) {
         const Layer& l = c->layers[i];
         if (!l.configured) continue;
@@ -1058,66 +1115,189 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
                 else if (l.tab >= 0 && finalize_up_supported(l.side, c->out_side)) cls = l.side == 32 ? 1 : 2;
                 else if (l.tab >= 0 && finalize_down2_supported(l.side, c->out_side)) cls = 4;
             }
-            if (cls == 3 && l.tab >= 0) max_side = std::max(max_side, l.side);
+            if (cls == 3 && l.tab >= 0) P.max_side = std::max(P.max_side, l.side);
             keys[cls].push_back(k);
-            ++total;
+            ++P.total;
         }
     }
-    if (total == 0) return fail(DAAM_E_NOMAPS, "no heat maps selected");
-    if (max_side > 128) return fail(DAAM_E_UNSUPPORTED, "map side %d > 128 not supported by finalize", max_side);
-    hipStream_t s = (hipStream_t)stream;
-    const size_t plane = (size_t)c->out_side * c->out_side;
-    const size_t out_bytes = sizeof(float) * c->tokens * plane;
-    static const int env_chunks = getenv("DAAM_FIN_CHUNKS") ? atoi(getenv("DAAM_FIN_CHUNKS")) : 0;
-    static const int env_up_chunks = getenv("DAAM_FIN_UP_CHUNKS") ? atoi(getenv("DAAM_FIN_UP_CHUNKS")) : 0;       // LDS up kernels only (A/B)
-    static const int env_pipe_chunks = getenv("DAAM_FIN_PIPE_CHUNKS") ? atoi(getenv("DAAM_FIN_PIPE_CHUNKS")) : 0; // pipelined x2 kernel only (A/B)
+    if (P.total == 0) return fail(DAAM_E_NOMAPS, "no heat maps selected");
+    if (P.max_side > 128) return fail(DAAM_E_UNSUPPORTED, "map side %d > 128 not supported by finalize", P.max_side);
     // x2 class on the matrix cores (fp16 planes, fp16-exact tap matrix)?
-    const bool mfma_up = !keys[1].empty() && c->acc_dtype == DAAM_F16 && keys[1][0].tab == c->up32_tab && c->d_up32_ops &&
-                         c->tab_fp16_exact[keys[1][0].tab] && !c->no_mfma_finalize;
+    P.mfma_up = !keys[1].empty() && c->acc_dtype == DAAM_F16 && keys[1][0].tab == c->up32_tab && c->d_up32_ops &&
+                c->tab_fp16_exact[keys[1][0].tab] && !c->no_mfma_finalize;
     // ... on the software-pipelined kernel (daam_finalize_pipe.hip): workgroup = (token, key chunk), every wave walks ALL keys
     // of its chunk from a pointer table padded with the all-zero plane to one even length >= 4 (+ what the ring prefetches
     // past the end).  ~1000 workgroups of 2 waves = one resident round at 2 waves per SIMD.
-    const bool pipe_up = mfma_up && !c->no_pipe_finalize && c->d_zero_planes;
-    int pipe_chunks = 0, pipe_nk = 0, pipe_stride = 0;
-    if (pipe_up) {
+    P.pipe_up = P.mfma_up && !c->no_pipe_finalize && c->d_zero_planes;
+    if (P.pipe_up) {
         const int n = (int)keys[1].size();
         const int want = env_pipe_chunks ? env_pipe_chunks : env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
-        pipe_chunks = std::max(1, std::min(want, (n + 7) / 8));
-        const int per = (n + pipe_chunks - 1) / pipe_chunks;
-        pipe_nk = std::max(4, (per + 1) & ~1);
-        pipe_stride = (pipe_nk + finalize_pipe_ring() + 2) & ~1;
+        P.pipe_chunks = std::max(1, std::min(want, (n + 7) / 8));
+        const int per = (n + P.pipe_chunks - 1) / P.pipe_chunks;
+        P.pipe_nk = std::max(4, (per + 1) & ~1);
+        P.pipe_stride = (P.pipe_nk + finalize_pipe_ring() + 2) & ~1;
     }
     // The same-size (64 x 64) keys ride along in the pipelined kernel (every wave adds its share of them to its accumulators
     // before the x2 loop) unless they outnumber the x2 keys 2 : 1 -- then they keep their own streaming kernel.
-    const bool fold_same = pipe_up && !keys[0].empty() && c->out_side == 64 && keys[0].size() <= 2 * keys[1].size() &&
-                           !c->no_fold_same;
-    const int same_per = fold_same ? ((int)keys[0].size() + pipe_chunks - 1) / pipe_chunks : 0;
-    size_t off = 0;
-    const size_t key_bytes = ((size_t)total * sizeof(FinKey) + 63) & ~size_t(63);
-    const size_t ptr_bytes = (size_t)pipe_chunks * pipe_stride * sizeof(unsigned long long);
-    const size_t bytes = key_bytes + ptr_bytes + (size_t)pipe_chunks * same_per * sizeof(unsigned long long);
-    HIP_TRY(c->ring.alloc(bytes, &off));
-    {
-        FinKey* dst = reinterpret_cast<FinKey*>(c->ring.host + off);
-        for (auto& v : keys) { memcpy(dst, v.data(), v.size() * sizeof(FinKey)); dst += v.size(); }
-        if (pipe_up) {
-            unsigned long long* pt = reinterpret_cast<unsigned long long*>(c->ring.host + off + key_bytes);
-            const unsigned long long zero = reinterpret_cast<unsigned long long>(c->d_zero_planes);
-            const int n = (int)keys[1].size(), per = (n + pipe_chunks - 1) / pipe_chunks;
-            for (int ch = 0; ch < pipe_chunks; ++ch)
-                for (int j = 0; j < pipe_stride; ++j) {
-                    const int k = ch * per + j;
-                    pt[(size_t)ch * pipe_stride + j] = (j < per && k < n) ? reinterpret_cast<unsigned long long>(keys[1][k].base) : zero;
-                }
-            unsigned long long* st = pt + (size_t)pipe_chunks * pipe_stride;
-            for (int ch = 0; ch < pipe_chunks; ++ch)
-                for (int j = 0; j < same_per; ++j) {
-                    const size_t k = (size_t)ch * same_per + j;
-                    st[(size_t)ch * same_per + j] = k < keys[0].size() ? reinterpret_cast<unsigned long long>(keys[0][k].base) : 0ull;
-                }
-        }
+    P.fold_same = P.pipe_up && !keys[0].empty() && c->out_side == 64 && keys[0].size() <= 2 * keys[1].size() && !c->no_fold_same;
+    P.same_per = P.fold_same ? ((int)keys[0].size() + P.pipe_chunks - 1) / P.pipe_chunks : 0;
+    P.key_bytes = ((size_t)P.total * sizeof(FinKey) + 63) & ~size_t(63);
+    P.ptr_bytes = (size_t)P.pipe_chunks * P.pipe_stride * sizeof(unsigned long long);
+    P.tab.assign(P.key_bytes + P.ptr_bytes + (size_t)P.pipe_chunks * P.same_per * sizeof(unsigned long long), 0);
+    FinKey* dst = reinterpret_cast<FinKey*>(P.tab.data());
+    for (auto& v : keys) {
+        if (!v.empty()) memcpy(dst, v.data(), v.size() * sizeof(FinKey));
+        dst += v.size();
     }
-    const FinKey* dev = reinterpret_cast<const FinKey*>(c->ring.dev + off);
+    if (P.pipe_up) {
+        unsigned long long* pt = reinterpret_cast<unsigned long long*>(P.tab.data() + P.key_bytes);
+        const unsigned long long zero = reinterpret_cast<unsigned long long>(c->d_zero_planes);
+        const int n = (int)keys[1].size(), per = (n + P.pipe_chunks - 1) / P.pipe_chunks;
+        for (int ch = 0; ch < P.pipe_chunks; ++ch)
+            for (int j = 0; j < P.pipe_stride; ++j) {
+                const int k = ch * per + j;
+                pt[(size_t)ch * P.pipe_stride + j] = (j < per && k < n) ? reinterpret_cast<unsigned long long>(keys[1][k].base) : zero;
+            }
+        unsigned long long* st = pt + (size_t)P.pipe_chunks * P.pipe_stride;
+        for (int ch = 0; ch < P.pipe_chunks; ++ch)
+            for (int j = 0; j < P.same_per; ++j) {
+                const size_t k = (size_t)ch * P.same_per + j;
+                st[(size_t)ch * P.same_per + j] = k < keys[0].size() ? reinterpret_cast<unsigned long long>(keys[0][k].base) : 0ull;
+            }
+    }
+    return 0;
+}
+
+// the device copy of the tables is the one these bytes were uploaded to, on this stream?
+static bool fin_cache_hit(const DaamCtx* c, const FinPlan& P, hipStream_t s)
+{
+    return !c->no_fin_cache && c->fin_tab_valid && c->fin_tab_stream == s && P.tab.size() == c->fin_tab_host.size() &&
+           memcmp(P.tab.data(), c->fin_tab_host.data(), P.tab.size()) == 0;
+}
+
+// may this call's tables replace the cached ones?  (not while kernels enqueued on ANOTHER stream may still be reading them)
+static bool fin_cacheable(const DaamCtx* c, const FinPlan& P, hipStream_t s)
+{
+    return !c->no_fin_cache && c->d_fin_tab && P.tab.size() <= DaamCtx::kFinTabCap && (!c->fin_tab_valid || c->fin_tab_stream == s);
+}
+
+// tables -> pinned ring -> d_fin_tab by the upload kernel (which also clears `zero`), in stream order
+static int fin_cache_upload(DaamCtx* c, const FinPlan& P, hipStream_t s, void* zero, size_t zero_bytes)
+{
+    size_t off = 0;
+    HIP_TRY(c->ring.alloc(P.tab.size(), &off));
+    memcpy(c->ring.host + off, P.tab.data(), P.tab.size());
+    c->fin_tab_valid = false;
+    hipError_t e = launch_upload(c->d_fin_tab, c->ring.host_dev + off, P.tab.size(), zero, zero_bytes, s);
+    (void)c->ring.release(s);                                  // the staging region is free once the upload kernel has run
+    if (e != hipSuccess) return fail((int)e, "table upload: %s", hipGetErrorString(e));
+    c->fin_tab_host = P.tab;
+    c->fin_tab_valid = true;
+    c->fin_tab_stream = s;
+    return 0;
+}
+
+static bool fin_out_zeroable(const DaamCtx* c, const float* out)
+{
+    const size_t out_bytes = sizeof(float) * c->tokens * (size_t)c->out_side * c->out_side;
+    return out_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+}
+
+int daam_finalize_prepare(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
+{
+    if (!c || !out) return fail(DAAM_E_INVALID, "NULL argument");
+    DeviceGuard on_device(c);
+    hipStream_t s = (hipStream_t)stream;
+    c->prep_out = c->fold_out = nullptr;
+    if (c->no_fin_cache || !fin_out_zeroable(c, out)) return 0;  // daam_finalize does everything itself
+    FinPlan P;
+    if (fin_plan(c, key_mask, P)) return 0;                      // nothing selected / unsupported: daam_finalize reports it
+    const size_t out_bytes = sizeof(float) * c->tokens * (size_t)c->out_side * c->out_side;
+    if (!fin_cache_hit(c, P, s)) {
+        if (!fin_cacheable(c, P, s)) return 0;
+        int rc = fin_cache_upload(c, P, s, out, out_bytes);      // first call of a geometry / selection: tables + zeroing now
+        if (rc) return rc;
+        c->prep_out = out;
+        c->prep_stream = s;
+        return 0;
+    }
+    if (!c->pending.empty()) {                                   // the table-upload kernel of the coming tap launch clears `out`
+        c->fold_out = out;
+        c->fold_bytes = out_bytes;
+        c->fold_stream = s;
+        return 0;
+    }
+    hipError_t e = launch_upload(nullptr, nullptr, 0, out, out_bytes, s);
+    if (e != hipSuccess) return fail((int)e, "output zeroing: %s", hipGetErrorString(e));
+    c->prep_out = out;
+    c->prep_stream = s;
+    return 0;
+}
+
+int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
+{
+    if (!c || !out) return fail(DAAM_E_INVALID, "NULL argument");
+    if (!c->pending.empty()) return fail(DAAM_E_STATE, "finalize with deferred taps pending: flush first");
+    DeviceGuard on_device(c);
+    hipStream_t s = (hipStream_t)stream;
+    // zeroed ahead of this call (daam_finalize_prepare, same buffer, same stream)?  One-shot.
+    const bool prepared = c->prep_out == out && c->prep_stream == s;
+    c->prep_out = c->fold_out = nullptr;
+    for (auto& l : c->layers)
+        if (l.configured) {
+            int zrc = ensure_zeroed(l, s);
+            if (zrc) return zrc;
+        }
+    constexpr int kClasses = kFinClasses;
+    FinPlan P;
+    {
+        int prc = fin_plan(c, key_mask, P);
+        if (prc) return prc;
+    }
+    auto& keys = P.keys;
+    const int total = P.total, max_side = P.max_side;
+    const bool mfma_up = P.mfma_up, pipe_up = P.pipe_up, fold_same = P.fold_same;
+    const int pipe_chunks = P.pipe_chunks, pipe_nk = P.pipe_nk, pipe_stride = P.pipe_stride, same_per = P.same_per;
+    const size_t key_bytes = P.key_bytes, ptr_bytes = P.ptr_bytes, bytes = P.tab.size();
+    const size_t plane = (size_t)c->out_side * c->out_side;
+    const size_t out_bytes = sizeof(float) * c->tokens * plane;
+    static const int env_chunks = fin_env("DAAM_FIN_CHUNKS");
+    static const int env_up_chunks = fin_env("DAAM_FIN_UP_CHUNKS");       // LDS up kernels only (A/B)
+    // the output is accumulated with atomics: it is zeroed by the table-upload launch unless daam_finalize_prepare had it done
+    const bool zero_in_upload = fin_out_zeroable(c, out);
+    if (!zero_in_upload && !prepared) {
+        hipError_t ze = hipMemsetAsync(out, 0, out_bytes, s);
+        if (ze != hipSuccess) return fail((int)ze, "output memset: %s", hipGetErrorString(ze));
+    }
+    if (c->profile) (void)hipEventRecord(c->prof_ev[1][0], s);    // timed: what this call launches (table upload + zeroing if needed, class kernels)
+    void* zero_ptr = (zero_in_upload && !prepared) ? out : nullptr;
+    const size_t zero_n = zero_ptr ? out_bytes : 0;
+    const char* tab_dev = nullptr;
+    bool ring_held = false;                                     // the tables sit in a ring region the class kernels read
+    if (fin_cache_hit(c, P, s)) {
+        tab_dev = c->d_fin_tab;
+        if (zero_ptr) {
+            hipError_t e = launch_upload(nullptr, nullptr, 0, zero_ptr, zero_n, s);
+            if (e != hipSuccess) return fail((int)e, "output zeroing: %s", hipGetErrorString(e));
+        }
+    } else if (fin_cacheable(c, P, s)) {
+        int rc = fin_cache_upload(c, P, s, zero_ptr, zero_n);
+        if (rc) return rc;
+        tab_dev = c->d_fin_tab;
+    } else {
+        size_t off = 0;
+        HIP_TRY(c->ring.alloc(bytes, &off));
+        memcpy(c->ring.host + off, P.tab.data(), bytes);
+        hipError_t ce = c->ring.commit(off, bytes, s, zero_ptr, zero_n);
+        if (ce != hipSuccess) {
+            (void)c->ring.release(s);
+            return fail((int)ce, "table upload: %s", hipGetErrorString(ce));
+        }
+        tab_dev = c->ring.dev + off;
+        ring_held = true;
+    }
+    auto release_tab = [&]() { if (ring_held) (void)c->ring.release(s); ring_held = false; };
+    const FinKey* dev = reinterpret_cast<const FinKey*>(tab_dev);
     c->last_block[1] = 256;
     c->last_grid[1] = 0;
     c->last_lds[1] = 0;
@@ -1179,20 +1359,6 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     }
     // SDXL-1024 in fp16: the same-size and the x2 class side by side in ONE launch
     const bool paired = mfma_up && !pipe_up && up_parts.size() == 1 && have[0] && !c->no_paired_finalize;
-    // the output is accumulated with atomics: zero it in the table-upload launch
-    const bool zero_in_upload = out_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    if (!zero_in_upload) {
-        hipError_t ze = hipMemsetAsync(out, 0, out_bytes, s);
-        if (ze != hipSuccess) { (void)c->ring.release(s); return fail((int)ze, "output memset: %s", hipGetErrorString(ze)); }
-    }
-    if (c->profile) (void)hipEventRecord(c->prof_ev[1][0], s);    // timed: table upload + zeroing + the class kernels
-    {
-        hipError_t ce = c->ring.commit(off, bytes, s, zero_in_upload ? out : nullptr, zero_in_upload ? out_bytes : 0);
-        if (ce != hipSuccess) {
-            (void)c->ring.release(s);
-            return fail((int)ce, "table upload: %s", hipGetErrorString(ce));
-        }
-    }
     // Several classes: the issue-bound x2 kernel keeps the caller's stream; every other class (HBM streams with few
     // registers: their waves fit beside the two heavy waves of a SIMD) goes to an auxiliary stream forked from / joined to the
     // caller's by events, launched FIRST -- SDXL-1024: 63 MB of same-size planes stream under 158 MB of x2 planes; SD-v1.5:
@@ -1215,18 +1381,18 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     auto launch_class = [&](int cls, hipStream_t ks, int* grid, int* lds) -> hipError_t {
         const FinLaunch& L = launches[cls];
         if (cls == 1 && pipe_up) {
-            FinPipeLaunch P;
-            P.key_ptrs = reinterpret_cast<const unsigned long long*>(c->ring.dev + off + key_bytes);
-            P.same_ptrs = fold_same ? reinterpret_cast<const unsigned long long*>(c->ring.dev + off + key_bytes + ptr_bytes) : nullptr;
-            P.same_per = same_per;
-            P.mfma_ops = c->d_up32_ops;
-            P.out = out;
-            P.n_chunks = pipe_chunks;
-            P.nk_pad = pipe_nk;
-            P.ptr_stride = pipe_stride;
-            P.tokens = c->tokens;
-            P.inv_n = L.inv_n;
-            return launch_finalize_up32_pipe(P, ks, grid);
+            FinPipeLaunch PL;
+            PL.key_ptrs = reinterpret_cast<const unsigned long long*>(tab_dev + key_bytes);
+            PL.same_ptrs = fold_same ? reinterpret_cast<const unsigned long long*>(tab_dev + key_bytes + ptr_bytes) : nullptr;
+            PL.same_per = same_per;
+            PL.mfma_ops = c->d_up32_ops;
+            PL.out = out;
+            PL.n_chunks = pipe_chunks;
+            PL.nk_pad = pipe_nk;
+            PL.ptr_stride = pipe_stride;
+            PL.tokens = c->tokens;
+            PL.inv_n = L.inv_n;
+            return launch_finalize_up32_pipe(PL, ks, grid);
         }
         if (cls == 1 && paired) return launch_finalize_up32_same(L, launches[0], ks, grid);
         if (cls == 1 && mfma_up) {
@@ -1261,17 +1427,17 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         }
         if (e != hipSuccess) {
             for (int i = 0; i < n_side; ++i) (void)hipStreamWaitEvent(s, c->aux_join[i], 0);
-            (void)c->ring.release(s);                      // the table region is reusable once whatever did launch has run
+            release_tab();                                 // the table region is reusable once whatever did launch has run
             return fail((int)e, "finalize launch (class %d): %s", cls, hipGetErrorString(e));
         }
         c->last_grid[1] += grid;
         c->last_lds[1] = std::max(c->last_lds[1], lds);
     }
     for (int i = 0; i < n_side; ++i)
-        if (hipStreamWaitEvent(s, c->aux_join[i], 0) != hipSuccess) { (void)c->ring.release(s); return fail(DAAM_E_STATE, "stream join failed"); }
+        if (hipStreamWaitEvent(s, c->aux_join[i], 0) != hipSuccess) { release_tab(); return fail(DAAM_E_STATE, "stream join failed"); }
     c->last_fin_side = n_side;
     if (c->profile) (void)hipEventRecord(c->prof_ev[1][1], s);
-    HIP_TRY(c->ring.release(s));
+    release_tab();
     return 0;
 }
 

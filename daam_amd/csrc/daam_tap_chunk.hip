@@ -21,12 +21,14 @@
 // registers after the LDS read (K x 0 = 0); a k-step that lies entirely past head_dim is skipped.
 #include "daam_tap16_softmax.h"
 
-// Experiment, off by default (-DDAAM_CHUNK_EARLY_DMA=1; prepared without a GPU at hand, not measured yet): the fetches of sub-step
-// u + 1 go out BEFORE the MFMAs of sub-step u instead of behind them -- the other K buffer is free once the barrier is passed, the
-// wave's own Q tile once its four operand reads have returned.  For the sub-steps of a wide head that have no softmax behind them
-// the DMA wait is fully exposed; this takes the MFMA phase off it.
-#ifndef DAAM_CHUNK_EARLY_DMA
-#define DAAM_CHUNK_EARLY_DMA 0
+// Debug aid (tools/exp/chunk_timeline.py; build with -DDAAM_CHUNK_TIMING): per-workgroup stamps -- 100 MHz reference counter at the start,
+// at the first step, after the last step and at the end; shader cycles wave 0 spent in the per-sub-step DMA wait + barrier and in the
+// whole loop; head_dim; HW_ID.
+#ifdef DAAM_CHUNK_TIMING
+__device__ unsigned long long daam_chunk_dbg[4096][8];
+#define DAAM_CT(i, v) do { if (threadIdx.x == 0 && wg < 4096) daam_chunk_dbg[wg][i] = (v); } while (0)
+#else
+#define DAAM_CT(i, v) do {} while (0)
 #endif
 
 namespace daam {
@@ -80,46 +82,6 @@ __device__ __forceinline__ void chunk_mfma(const unsigned char* kb, const unsign
     }
 }
 
-// DAAM_CHUNK_EARLY_DMA: the same MFMAs with the Q operands read up front and `issue` (the next sub-step's DMAs) called between the
-// operand reads and the MFMAs
-template <typename IN, bool FIRST, typename F>
-__device__ __forceinline__ void chunk_mfma_early(const unsigned char* kb, const unsigned char* qtile, int f_rd, bool partial, int vc, int h,
-                                                 floatx4 (&c0)[5], floatx4 (&c1)[5], F&& issue)
-{
-    const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool two = !partial || vc > 4;                                   // wave-uniform
-    half8 q00 = *reinterpret_cast<const half8*>(qtile + f_rd);
-    half8 q10 = *reinterpret_cast<const half8*>(qtile + 16 * kCkRow + f_rd);
-    half8 q01 = zero, q11 = zero;
-    if (two) {
-        q01 = *reinterpret_cast<const half8*>(qtile + (f_rd ^ 64));
-        q11 = *reinterpret_cast<const half8*>(qtile + 16 * kCkRow + (f_rd ^ 64));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // the tile's reads have returned: it may be overwritten
-    issue();
-    if (partial && vc < 4 && h >= vc) { q00 = zero; q10 = zero; }
-    if (partial && 4 + h >= vc) { q01 = zero; q11 = zero; }
-#pragma unroll
-    for (int mt = 0; mt < 5; ++mt) {
-        const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kCkRow + f_rd);
-        if constexpr (FIRST) {
-            c0[mt] = IN::mfma(a0, q00, floatx4{0, 0, 0, 0});
-            c1[mt] = IN::mfma(a0, q10, floatx4{0, 0, 0, 0});
-        } else {
-            c0[mt] = IN::mfma(a0, q00, c0[mt]);
-            c1[mt] = IN::mfma(a0, q10, c1[mt]);
-        }
-    }
-    if (two) {
-#pragma unroll
-        for (int mt = 0; mt < 5; ++mt) {
-            const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kCkRow + (f_rd ^ 64));
-            c0[mt] = IN::mfma(a1, q01, c0[mt]);
-            c1[mt] = IN::mfma(a1, q11, c1[mt]);
-        }
-    }
-}
-
 // IN = InF16 / InBF16 (daam_tap16_softmax.h: the MFMA and the softmax rounding points of the pipeline dtype; bf16 has one softmax
 // flavour and keeps its values in f32 registers: 3 waves per SIMD)
 template <typename IN, typename ACC_T, bool FAST_EXP>
@@ -141,6 +103,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     if (L.wgs_per_xcd > 0) wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
     else wg = (int)blockIdx.x < L.total_wgs ? (int)blockIdx.x : -1;
     if (wg < 0) return;
+    DAAM_CT(0, __builtin_amdgcn_s_memrealtime());
     tap_mark_started(L);
     TapLayer lay;
     const bool table = L.layers != nullptr;
@@ -276,34 +239,35 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     //   last chunk the softmax of the two pixel groups runs with those DMAs in flight.
     dma(0, 0, 0);
     int buf = 0;
+#ifdef DAAM_CHUNK_TIMING
+    unsigned long long waited = 0, w0 = 0;
+    const unsigned long long loop0 = __builtin_amdgcn_s_memtime();
+    DAAM_CT(1, __builtin_amdgcn_s_memrealtime());
+#define DAAM_CW0() w0 = __builtin_amdgcn_s_memtime()
+#define DAAM_CW1() waited += __builtin_amdgcn_s_memtime() - w0
+#else
+#define DAAM_CW0() do {} while (0)
+#define DAAM_CW1() do {} while (0)
+#endif
     for (int s = 0; s < n_steps; ++s) {
         floatx4 c0[5], c1[5];
         const int s_next = min(s + 1, n_steps - 1);           // branch-free: the last step re-fetches itself
+        DAAM_CW0();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#if DAAM_CHUNK_EARLY_DMA
-        chunk_mfma_early<IN, true>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && n_ch == 1, vc, h, c0, c1,
-                                   [&] { if (n_ch > 1) dma(s, 1, buf ^ 1); else dma(s_next, 0, buf ^ 1); });
-        buf ^= 1;
-        for (int c = 1; c < n_ch; ++c) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            chunk_mfma_early<IN, false>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && c == n_ch - 1, vc, h, c0, c1,
-                                        [&] { if (c + 1 < n_ch) dma(s, c + 1, buf ^ 1); else dma(s_next, 0, buf ^ 1); });
-            buf ^= 1;
-        }
-#else
+        DAAM_CW1();
         chunk_mfma<IN, true>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && n_ch == 1, vc, h, c0, c1);
         buf ^= 1;
         if (n_ch > 1) dma(s, 1, buf); else dma(s_next, 0, buf);
         for (int c = 1; c < n_ch; ++c) {
+            DAAM_CW0();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            DAAM_CW1();
             chunk_mfma<IN, false>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && c == n_ch - 1, vc, h, c0, c1);
             buf ^= 1;
             if (c + 1 < n_ch) dma(s, c + 1, buf); else dma(s_next, 0, buf);
         }
-#endif
         if constexpr (IN::kBf16) {
             softmax20_accumulate_bf16<ACC_T>(c0, lay, h, run0);
             softmax20_accumulate_bf16<ACC_T>(c1, lay, h, run1);
@@ -312,6 +276,18 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
         }
     }
+#ifdef DAAM_CHUNK_TIMING
+    DAAM_CT(2, __builtin_amdgcn_s_memrealtime());
+    DAAM_CT(4, waited);
+    DAAM_CT(5, __builtin_amdgcn_s_memtime() - loop0);
+    DAAM_CT(6, (unsigned long long)d | ((unsigned long long)n_steps << 16));
+    {
+        unsigned hw_id, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        DAAM_CT(7, (unsigned long long)hw_id | ((unsigned long long)xcc << 32));
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last (redundant) fetch has landed before the staging tile reuses the space
     __syncthreads();                                          // all K reads done
 
@@ -331,6 +307,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             *as_global_rw<float4v>(acc + (size_t)row * lay.hw + p0 + col) =
                 *reinterpret_cast<const float4v*>(stage + row * kMfmaPixels + col);
     }
+    DAAM_CT(3, __builtin_amdgcn_s_memrealtime());
 }
 
 // q_extent = elements from the tensor's first to past its last addressed Q element (batch * q_sb): byte offsets stay in 32 bits
@@ -389,3 +366,9 @@ hipError_t launch_tap_chunk(const TapLaunch& L0, int in_dtype, int acc_dtype, in
 }
 
 }  // namespace daam
+
+#ifdef DAAM_CHUNK_TIMING
+extern "C" __attribute__((visibility("default"))) int daam_debug_dump_chunk(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(daam::daam_chunk_dbg), sizeof(daam::daam_chunk_dbg));
+}
+#endif

@@ -484,16 +484,20 @@ class HeatMapEngine:
         cur.wait_stream(rec)
         return cur.cuda_stream, rec
 
-    def flush(self) -> None:
+    def flush(self, _before_launch=None) -> bool:
         """Run every recorded (deferred) tap; the held Q/K references are dropped afterwards
-        (stream order keeps their memory valid until the kernel has consumed it)."""
+        (stream order keeps their memory valid until the kernel has consumed it).  ``_before_launch(stream)`` is called between
+        handing the recorded calls to the library and the launch (``global_heat_map`` announces its output there, so that the
+        launch's table-upload kernel clears it).  Returns whether anything was launched."""
         if self._fast is not None:
             n, la, qa, ka, da = self._fast.buffers()
             if self.ctx is None or n == 0:
-                return
+                return False
             try:
                 stream, rec_stream = self._launch_stream()
                 nat.check(self.lib.daam_tap_qk_enqueue_many(self.ctx, n, la, qa, ka, da))
+                if _before_launch is not None:
+                    _before_launch(stream)
                 nat.check(self.lib.daam_tap_flush(self.ctx, stream))
                 if rec_stream is not None:
                     # the Q / K blocks return to the recording stream's allocator pool: not before the tap has read them
@@ -501,11 +505,11 @@ class HeatMapEngine:
                 self._set_window(self.defer_steps)
             finally:
                 self._drop_recorded()
-            return
+            return True
         rec = self._rec
         n = len(rec)
         if self.ctx is None or n == 0:
-            return
+            return False
         if self._check_versions:
             for layer, q, k, _d, qv, kv in rec:
                 if q._version != qv or k._version != kv:
@@ -522,12 +526,15 @@ class HeatMapEngine:
             stream, rec_stream = self._launch_stream()
             nat.check(self.lib.daam_tap_qk_enqueue_many(self.ctx, n, layers.ctypes.data, qp.ctypes.data, kp.ctypes.data,
                                                         dp.ctypes.data))
+            if _before_launch is not None:
+                _before_launch(stream)
             nat.check(self.lib.daam_tap_flush(self.ctx, stream))
             if rec_stream is not None:
                 rec_stream.wait_stream(self._current_stream())
             self._window = self.defer_steps
         finally:
             self._drop_recorded()
+        return True
 
     def _drop_recorded(self) -> None:
         self._rec.clear()
@@ -593,7 +600,6 @@ class HeatMapEngine:
         fset = {0, 1, 2, 4, 8, 16, 32, 64} if factors is None else set(factors)
         if self.ctx is None or not self.touched:
             raise LookupError('no heat maps')
-        self.flush()
         # key mask in the library's key order (configured layers by index, heads inside); cached per
         # selection -- building it costs more host time than the finalize kernels take on the device
         sel = (tuple(sorted(fset)), head_idx, layer_idx, tuple(self.touched), len(self.layer_info))
@@ -618,9 +624,18 @@ class HeatMapEngine:
             cached = self._mask_cache[sel] = (mask, n)
         mask, n = cached
         if n == 0:
+            self.flush()
             raise LookupError('no heat maps')
         out = torch.empty(self.tokens, self.out_side, self.out_side, dtype=torch.float32, device=self.device)
-        nat.check(self.lib.daam_finalize(self.ctx, mask, out.data_ptr(), self.stream))
+        # the output is announced BEFORE the deferred taps go out: the launch's table-upload kernel clears it and the key tables
+        # stay on the device between generations, so the finalize call below is its class kernel(s) only (daam_finalize_prepare)
+        optr = out.data_ptr()
+
+        def announce(stream):
+            nat.check(self.lib.daam_finalize_prepare(self.ctx, mask, optr, stream))
+        if not self.flush(_before_launch=announce):
+            announce(self.stream)
+        nat.check(self.lib.daam_finalize(self.ctx, mask, optr, self.stream))
         return out
 
     def normalize_(self, maps: torch.Tensor) -> torch.Tensor:

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DAAM_ABI_VERSION 4
+#define DAAM_ABI_VERSION 5
 
 /* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
 #define DAAM_API __attribute__((visibility("default")))
@@ -160,6 +160,14 @@ DAAM_API int daam_attend(DaamCtx* ctx, int layer, const void* q, const void* k, 
  * mean over selected keys of clamp(bicubic(sum_plane), 0).  `out` is overwritten. */
 DAAM_API int daam_key_offset(DaamCtx* ctx, int layer, int* offset, int* total);
 DAAM_API int daam_finalize(DaamCtx* ctx, const uint8_t* key_mask, float* out, void* stream);
+/* Optional, ABI v5: announce the `key_mask` / `out` / `stream` of the daam_finalize call that follows, BEFORE the deferred taps are
+ * launched (between daam_tap_qk_enqueue* and daam_tap_flush), or any time before daam_finalize when nothing is pending.  The key /
+ * pointer tables of the selection are kept on the device between calls (a generation's compute_global_heat_map, trace.py:103-126,
+ * selects the same keys at the same addresses as the previous one) and `out` is cleared by the table-upload kernel of the tap
+ * launch, so that daam_finalize itself is its class kernel(s) only.  `out` must stay allocated and untouched until that
+ * daam_finalize; the announcement is one-shot and dropped by daam_reset, by a daam_finalize with other arguments (which then does
+ * everything itself, as without this call) and by the next daam_tap_flush. */
+DAAM_API int daam_finalize_prepare(DaamCtx* ctx, const uint8_t* key_mask, float* out, void* stream);
 
 /* trace.py:129-130: maps[:n_rows] / (maps[1:n_rows-1].sum(0) + 1e-6), in place on the first
  * n_rows planes of `maps` [*, side, side] fp32. */

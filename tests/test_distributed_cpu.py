@@ -53,6 +53,16 @@ def test_gather_world2_gloo(tmp_path, n_items):
         assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize('world,n_items', [(3, 7), (3, 2), (8, 33), (8, 5)])
+def test_gather_ragged_tails_gloo(tmp_path, world, n_items):
+    """More than two ranks, shards of unequal length (3 ranks x 7 items: 3 / 2 / 2; 3 x 2 and 8 x 5: ranks with NOTHING, whose
+    contribution is all padding; 8 x 33: 5 / 4 x 7): every rank gets every item, in item order."""
+    mp.spawn(_worker, args=(world, _free_port(), n_items, str(tmp_path)), nprocs=world, join=True)
+    want = torch.stack([torch.full((3, 4, 4), float(i)) + torch.arange(3).view(3, 1, 1) / 10 for i in range(n_items)])
+    for r in range(world):
+        assert torch.equal(torch.load(os.path.join(str(tmp_path), f'r{r}.pt')), want)
+
+
 def test_gather_single_process_passthrough():
     x = torch.randn(3, 2, 2)
     assert gather_heat_maps(x, 3) is x
@@ -73,16 +83,18 @@ def _comm_worker(rank, world, port, out_dir):
         got = comm.all_gather(mine)                        # rank-major: rank r's maps are rows [3r, 3r + 3)
         assert torch.equal(got[rank * 3:(rank + 1) * 3], mine)
         slowest = comm.max(1.0 + rank)
+        assert f'world_size {world}' in comm.library()
         torch.save(dict(got=got, slowest=slowest), os.path.join(out_dir, f'c{rank}.pt'))
     finally:
         comm.close()
 
 
-def test_bench_comm_world2_gloo(tmp_path):
-    """bench.py's collective layer (barrier, all_gather of the final maps, MAX of the elapsed times) with two ranks."""
-    world = 2
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_comm_gloo(tmp_path, world):
+    """bench.py's collective layer (barrier, all_gather of the final maps, MAX of the elapsed times) with two and with eight ranks
+    (the driver's largest launch)."""
     mp.spawn(_comm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     want = torch.cat([torch.full((3, 2, 4, 4), float(r)) + torch.arange(3).view(3, 1, 1, 1) / 10 for r in range(world)])
     for r in range(world):
         rec = torch.load(os.path.join(str(tmp_path), f'c{r}.pt'))
-        assert torch.equal(rec['got'], want) and rec['slowest'] == 2.0
+        assert torch.equal(rec['got'], want) and rec['slowest'] == float(world)

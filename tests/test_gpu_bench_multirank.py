@@ -33,10 +33,27 @@ def test_bench_two_ranks_one_device():
     assert two['steps'] == 3 and two['scaling'] == 'weak' and two['metric'] == one['metric']
     assert 'ONE DEVICE' in two['config']['collective'] and 'gloo' in two['config']['collective']
     assert two['config']['parallelism'] == 'prompt-shard x2'
+    assert one['config']['collective_world_size'] == 1 and one['config']['collective_library'] is None
+    assert two['config']['collective_world_size'] == 2 and two['config']['collective_library'].startswith('gloo')
+    # the single-rank line measured its HBM traffic in the run (two children under rocprofv3 --pmc)
+    assert one['roofline']['traffic_measured_in_run'] is True, one['roofline'].get('traffic_in_run_note')
+    assert 0.9 <= one['roofline']['traffic_over_algorithmic'] <= 1.3, one['roofline']
     # two ranks share one GPU: the aggregate rate is about the single-rank rate (never the 2x of two devices), minus the
     # host-staged gather of 2 x 3 maps inside the timed region
     assert 0.3 * one['value'] <= two['value'] <= 1.5 * one['value'], (one['value'], two['value'])
     assert two['roofline']['launches_per_generation'] == 1 and two['roofline']['frac'] > 0.1
+
+
+def test_bench_eight_ranks_one_device():
+    """The driver's largest launch shape -- ``--gpus 8`` -- on the one-GPU box: eight ranks under torch.distributed.run, rank-seeded
+    inputs (4 step sets = 1.6 GB per rank), the gather of 8 x 3 maps, the MAX reduce, every rank's slice check.  If the 8-rank path
+    has a defect that two ranks do not show (port / rendezvous, gather layout, rank-major slicing), it fails here and not on the
+    driver's node."""
+    rec = _bench('--gpus', '8', '--dist-backend', 'gloo', '--shared-device', '--pool', '4', timeout=900)
+    assert rec['n_gpus'] == 8 and rec['steps'] == 3 and rec['scaling'] == 'weak'
+    assert rec['config']['parallelism'] == 'prompt-shard x8'
+    assert rec['config']['collective_world_size'] == 8 and 'world_size 8' in rec['config']['collective_library']
+    assert rec['value'] > 0 and rec['roofline']['launches_per_generation'] == 1
 
 
 def test_bench_refuses_more_gpus_than_visible():

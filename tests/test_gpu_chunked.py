@@ -108,13 +108,11 @@ def test_chunked_sd15_flush_is_one_kernel_and_bit_identical(monkeypatch):
     assert np.abs(tot - 20).max() < 0.25
 
 
-@pytest.mark.skipif(not __import__('os').environ.get('DAAM_TEST_UNVALIDATED'),
-                    reason='the bf16 instantiation of tap_chunk_kernel was added after the round\'s GPU time had run out: it is opt-in '
-                           '(DAAM_TAP_CHUNKED=1) and this test is what validates it -- run with DAAM_TEST_UNVALIDATED=1')
 @pytest.mark.parametrize('accumulate', ['exact', 'float32'])
 def test_chunked_bf16_layers(monkeypatch, accumulate):
-    """bf16 pipelines: head_dim <= 64 bit-identical to the bf16 head_dim-64 kernel; wider heads (on the any-shape kernel by default:
-    f32 FMA dot products, another summation order) within two bf16 ulps of the sums."""
+    """bf16 pipelines: head_dim <= 64 bit-identical to the bf16 head_dim-64 kernel; wider heads (DAAM_TAP_CHUNKED=0 leaves them on the
+    any-shape kernel: f32 FMA dot products, another summation order) within two bf16 ulps of the sums.  First run on the chip in
+    round 4; since then the DEFAULT for bf16 layers with head_dim > 64, and a bf16 launch that mixes head dims is one kernel."""
     shapes = [(8, 1024, 64), (8, 4096, 40), (8, 1024, 80), (8, 256, 160), (2, 144, 48)]
     g = torch.Generator(device=DEV).manual_seed(3)
     sets = [[(torch.randn(2, hw, h * d, generator=g, device=DEV).bfloat16(), torch.randn(2, 77, h * d, generator=g, device=DEV).bfloat16())
@@ -134,3 +132,9 @@ def test_chunked_bf16_layers(monkeypatch, accumulate):
         else:
             tol = 2.0 ** -7 * b.abs() + 2.0 ** -9 if accumulate == 'exact' else 2.0 ** -8 * b.abs() + 2.0 ** -9
             assert bool(((a - b).abs() <= tol).all()), (key, float((a - b).abs().max()))
+    dflt_eng = _engine(monkeypatch, None, len(shapes), accumulate, 8)
+    dflt, dflush = _run(dflt_eng, shapes, sets, rounds=2)
+    dflt_eng.close()
+    assert dflush['kernels'] == 1 and dflush['side_streams'] == 0, dflush
+    for key in got:
+        assert torch.equal(got[key], dflt[key]), key

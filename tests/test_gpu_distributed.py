@@ -70,3 +70,16 @@ def test_trace_prompts_two_ranks_one_device(backend, tmp_path, single_process_ma
         assert got['maps'].shape == want.shape
         # same kernels on the same inputs; the f32 atomics of finalize may add in another order
         assert torch.allclose(got['maps'], want, rtol=0, atol=1e-6)
+
+
+def test_trace_prompts_three_ranks_ragged_tail(tmp_path, single_process_maps):
+    """Five prompts over THREE ranks (shards of 2 / 2 / 1): the shorter shard goes through ``gather_heat_maps``' padding, every rank
+    ends up with all five maps in prompt order -- nothing above two ranks had run on any backend before round 4."""
+    want, want_rows = single_process_maps
+    outs = _run_ranks('gloo', 3, tmp_path)
+    for rc, o, e in outs:
+        assert rc == 0, e[-2000:]
+    for r in range(3):
+        got = torch.load(os.path.join(str(tmp_path), f'r{r}.pt'))
+        assert got['rows'] == want_rows and got['maps'].shape == want.shape
+        assert torch.allclose(got['maps'], want, rtol=0, atol=1e-6)

@@ -306,6 +306,65 @@ def test_finalize_pipe_key_counts(n_keys, fold, monkeypatch):
     eng.close()
 
 
+def test_finalize_prepare_paths(monkeypatch):
+    """ABI v5, daam_finalize_prepare: the key tables stay on the device between calls and the output is cleared by the upload
+    kernel of the tap launch in front of the finalize -- generation after generation (first call of a selection: tables + zeroing
+    at once; later ones: zeroing folded into the tap launch, or a stand-alone zeroing when nothing is pending), across changing
+    selections, into RECYCLED output memory (torch hands the previous map's block back: a skipped zeroing would double the map),
+    and against the same engine with DAAM_NO_FIN_CACHE=1 (every call uploads + zeroes itself, round 3's behaviour).  Also the raw
+    C ABI: an announcement for one buffer followed by a finalize into ANOTHER one must not rely on it."""
+    import ctypes
+    from daam_amd import _native as nat
+    from daam_amd import engine as E
+    rng = np.random.default_rng(77)
+    shapes = [(2, 32, 64), (2, 64, 64), (3, 16, 40)]                 # heads, side, head_dim
+    steps = [[_qk(rng, 2, h, s * s, d, np.float16) for (h, s, d) in shapes] for _ in range(3)]
+    dev_steps = [[(_dev(q), _dev(k)) for q, k in st] for st in steps]
+
+    def generation(eng, n):
+        eng.clear()
+        for t in range(n):
+            for layer, ((h, s, d), (q, k)) in enumerate(zip(shapes, dev_steps[t % 3])):
+                eng.tap_qk(layer, q, k, h, d ** -0.5, 64 // s)
+
+    selections = [dict(), dict(factors=[2]), dict(head_idx=1), dict(), dict(), dict(layer_idx=0), dict()]
+    results = {}
+    for cache in ('1', '0'):
+        monkeypatch.setenv('DAAM_NO_FIN_CACHE', '1' if cache == '0' else '0')
+        E.release_parked_contexts()
+        eng = _engine(n_layers=len(shapes), defer_steps=8)
+        got = []
+        for g, kw in enumerate(selections):
+            generation(eng, 2 + g % 2)
+            a = eng.global_heat_map(**kw)                            # taps pending: prepare -> flush (folds) -> finalize
+            got.append(a.clone())
+            del a                                                   # its block goes back to the allocator ...
+            b = eng.global_heat_map(**kw)                            # ... and is handed out again; nothing pending now
+            assert torch.allclose(b, got[-1], rtol=0, atol=2e-6), (cache, g, kw)
+            del b
+        results[cache] = got
+        if cache == '1':
+            # raw ABI: announce buffer A, finalize into B (filled with garbage): B must come out right; then the announced form
+            lib, stream = eng.lib, eng.stream
+            A = torch.full((77, 64, 64), 7.0, device=DEV)
+            B = torch.full((77, 64, 64), -3.0, device=DEV)
+            nat.check(lib.daam_finalize_prepare(eng.ctx, None, A.data_ptr(), stream))
+            nat.check(lib.daam_finalize(eng.ctx, None, B.data_ptr(), stream))
+            assert torch.allclose(B, got[-1], rtol=0, atol=2e-6)
+            A.fill_(9.0)
+            nat.check(lib.daam_finalize_prepare(eng.ctx, None, A.data_ptr(), stream))
+            nat.check(lib.daam_finalize(eng.ctx, None, A.data_ptr(), stream))
+            assert torch.allclose(A, got[-1], rtol=0, atol=2e-6)
+            # an announcement is one-shot: the next finalize into the same buffer zeroes it itself
+            nat.check(lib.daam_finalize(eng.ctx, None, A.data_ptr(), stream))
+            assert torch.allclose(A, got[-1], rtol=0, atol=2e-6)
+        eng.close()
+    for g, (a, b) in enumerate(zip(results['1'], results['0'])):
+        assert float(b.abs().max()) > 0
+        assert torch.allclose(a, b, rtol=0, atol=2e-6), (g, float((a - b).abs().max()))
+    E.release_parked_contexts()
+
+
 def test_views_survive_clear_and_next_generation():
     """``all_heat_maps`` hands out views of the live sums; like the reference's tensors (heatmap.py:170-172: clear() drops the
     dict, tensors handed out before live on) they must keep their values through clear() AND through the next
