@@ -369,6 +369,6 @@ hipError_t launch_tap_chunk(const TapLaunch& L0, int in_dtype, int acc_dtype, in
 
 #ifdef DAAM_CHUNK_TIMING
 extern "C" __attribute__((visibility("default"))) int daam_debug_dump_chunk(unsigned long long* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(daam::daam_chunk_dbg), sizeof(daam::daam_chunk_dbg));
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(daam_chunk_dbg), sizeof(daam_chunk_dbg));
 }
 #endif
