@@ -48,7 +48,7 @@ hipError_t launch_mask_overlap(const float*, int, int, const float*, int, int, i
 bool attend_d64_supported(int in_dtype, int head_dim, int tokens, const int64_t* strides, int n_strides, const void* const* ptrs, int n_ptrs);
 hipError_t launch_attend_d64(const AttendLaunch&, int in_dtype, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
 hipError_t launch_clock_monitor(unsigned long long* samples, int n_samples, int period_us, hipStream_t);
-hipError_t launch_start_gate(const unsigned* counter, unsigned target, int timeout_us, hipStream_t);
+hipError_t launch_start_gate(const unsigned* counter, unsigned target, int timeout_us, unsigned* timeouts, hipStream_t);
 constexpr int kClockMaxSamples = 4096;
 hipError_t launch_word(const float*, int, const int32_t*, int, float*, float*, int, int, int, float, float*,
                        hipStream_t);
@@ -233,6 +233,8 @@ struct DaamCtx {
     hipEvent_t aux_fork = nullptr, aux_join[kAux] = {nullptr, nullptr, nullptr};
     unsigned* d_started = nullptr;     // start gate of multi-kernel flushes: workgroups of side kernels started so far (wraps)
     unsigned started_target = 0;       // ... and how many the host has launched
+    unsigned* gate_timeouts = nullptr; // pinned, device-mapped: gates that gave up after their 200 us (the side kernels were NOT running beside them)
+    unsigned* gate_timeouts_dev = nullptr;
     int no_start_gate = 0;             // debugging / A-B: DAAM_NO_START_GATE=1
     int no_side_stream = 0;
 
@@ -349,6 +351,16 @@ static hipError_t ensure_aux(DaamCtx* c)
         if (ae == hipSuccess) ae = hipMemset(c->d_started, 0, sizeof(unsigned));
         c->started_target = 0;
     }
+    if (ae == hipSuccess && !c->gate_timeouts) {
+        // best effort: without the word the gate still works, its timeouts just go unnoticed
+        if (hipHostMalloc(reinterpret_cast<void**>(&c->gate_timeouts), sizeof(unsigned), hipHostMallocMapped) == hipSuccess) {
+            *c->gate_timeouts = 0;
+            if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->gate_timeouts_dev), c->gate_timeouts, 0) != hipSuccess)
+                c->gate_timeouts_dev = nullptr;
+        } else {
+            c->gate_timeouts = nullptr;
+        }
+    }
     return ae;
 }
 
@@ -427,6 +439,7 @@ int daam_ctx_destroy(DaamCtx* c)
             if (ev) (void)hipEventDestroy(ev);
     if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
     if (c->d_started) (void)hipFree(c->d_started);
+    if (c->gate_timeouts) (void)hipHostFree(c->gate_timeouts);
     for (auto& ev : c->aux_join)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& st : c->aux_stream)
@@ -977,6 +990,13 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     int n_side = 0;
     // start gate: the side kernels' workgroups count themselves in, the main kernel waits (one wave, bounded) until they are
     // resident -- only for the kernels that carry the counter (the MFMA kinds)
+    // a gate of an earlier flush ran into its timeout: the auxiliary streams do not run beside the caller's here (one hardware queue,
+    // GPU_MAX_HW_QUEUES) -- every gated flush would pay the 200 us for nothing, so the context stops using it (said once)
+    if (!c->no_start_gate && c->gate_timeouts && *reinterpret_cast<volatile unsigned*>(c->gate_timeouts) != 0) {
+        c->no_start_gate = 1;
+        fprintf(stderr, "libdaam_hip: the start gate of a multi-kernel tap launch timed out (side streams not concurrent with the caller's "
+                        "stream); gate disabled for this context\n");
+    }
     bool gate = forked && !main_first && !c->no_start_gate && c->d_started;
     for (size_t i = 0; i < prepared.size(); ++i)
         if (i != main_idx && !prepared[i].kd) gate = false;
@@ -991,7 +1011,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             if (gate) { pr.L.started = c->d_started; gate_wgs += (unsigned)pr.L.total_wgs; }
         } else if (gate && gate_wgs) {
             c->started_target += gate_wgs;                     // unsigned wrap-around is fine: the kernel compares differences
-            hipError_t ge = launch_start_gate(c->d_started, c->started_target, 200, s);
+            hipError_t ge = launch_start_gate(c->d_started, c->started_target, 200, c->gate_timeouts_dev, s);
             if (ge != hipSuccess) { rc = fail((int)ge, "start gate: %s", hipGetErrorString(ge)); break; }
         }
         int grid = 0;
@@ -1011,6 +1031,9 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         for (size_t i = 0; i < order.size(); ++i)
             if (kind[i] == pr.kd) { c->layers[order[i]].dirty = true; c->layers[order[i]].zero_pending = false; }
     }
+    // a flush that failed part-way may have announced side workgroups that never started: counter and target would disagree for
+    // good (every later gate a silent no-op or a full timeout), so the context stops gating
+    if (rc && gate) c->no_start_gate = 1;
     // join (after the main kernel is enqueued): the caller's stream continues when every side kernel is done
     for (int i = 0; i < n_side; ++i)
         if (hipStreamWaitEvent(s, c->aux_join[i], 0) != hipSuccess) rc = rc ? rc : fail(DAAM_E_STATE, "stream join failed");

@@ -32,63 +32,17 @@ __device__ __forceinline__ constexpr int v_slot_byte(int t) {
 
 // fp16 probabilities of the lane's 20 token slots (slot pairs), the arithmetic of softmax20_accumulate (daam_tap_d64.hip)
 // up to the point where that one adds them to the running sums; tests/test_gpu_attend.py holds the two to bit-identical sums
-template <bool FAST_EXP>
+template <bool FAST_EXP, bool PREMASKED>
 __device__ __forceinline__ void softmax20_probs(const floatx4 (&c)[5], float scale, int round_logits, int h,
                                                 half2v (&ph)[kSlots16 / 2])
 {
     if constexpr (FAST_EXP) {
-        const bool pow2 = (__float_as_uint(scale) & 0x007fffffu) == 0;          // wave-uniform
-        half2v xh[kSlots16 / 2];
-        if (pow2) {
-            // compiler-visible conversions: first VALU read of the MFMA results (MFMA -> VALU wait states)
-#pragma unroll
-            for (int mt = 0; mt < 5; ++mt) {
-                xh[2 * mt] = __builtin_convertvector(float2v{c[mt][0], c[mt][1]}, half2v);
-                xh[2 * mt + 1] = __builtin_convertvector(float2v{c[mt][2], c[mt][3]}, half2v);
-            }
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < 5; ++mt) {
-                xh[2 * mt] = cvt_pk_rne(float2v{c[mt][0], c[mt][1]} * scale);
-                xh[2 * mt + 1] = cvt_pk_rne(float2v{c[mt][2], c[mt][3]} * scale);
-            }
+        if (round_logits) {                                              // wave-uniform; f32 logits (upcast_attention) take the other flavour's code
+            softmax20_probs_fast<PREMASKED>(c, scale, h, ph);
+            return;
         }
-        if (h == 3) {                                                   // tokens 77, 78, 79
-            const _Float16 ninf = -(_Float16)__builtin_inff();
-            xh[8][1] = ninf;
-            xh[9] = half2v{ninf, ninf};
-        }
-        const float L = 1.44269502162933349609375f * (pow2 ? scale : 1.0f);
-        float2v ev[kSlots16 / 2];
-        auto exps = [&](float nmL) -> float {
-            float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < kSlots16 / 2; i += 2) {
-                ev[i] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][0], L, nmL)),
-                                __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][1], L, nmL))};
-                ev[i + 1] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][0], L, nmL)),
-                                    __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][1], L, nmL))};
-                sa += ev[i];
-                sb += ev[i + 1];
-            }
-            sa += sb;
-            return quad_sum(sa[0] + sa[1]);
-        };
-        float tot = exps(-quad_bcast0((float)xh[0][0]) * L);
-        if (__builtin_expect(!(tot <= 0x1p100f), 0)) {                   // large, inf or NaN: redo with the row maximum
-            half2v ma = xh[0], mb = xh[1];
-#pragma unroll
-            for (int i = 2; i < kSlots16 / 2; i += 2) {
-                ma = pk_max(ma, xh[i]);
-                mb = pk_max(mb, xh[i + 1]);
-            }
-            ma = pk_max(ma, mb);
-            tot = exps(-quad_max(fmaxf((float)ma[0], (float)ma[1])) * L);
-        }
-        const float inv = __builtin_amdgcn_rcpf(tot);
-#pragma unroll
-        for (int i = 0; i < kSlots16 / 2; ++i) ph[i] = cvt_pk_rne(ev[i] * inv);   // probs.to(dtype)
-    } else {
+    }
+    {
         float x[kSlots16];
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt)
@@ -223,10 +177,11 @@ __global__ __launch_bounds__(256, 2) void attend_kernel(const AttendLaunch L)
     // ---- S^T = K Q^T ----------------------------------------------------------------------------------------------
     const unsigned char* a_rd = kbuf + j * S::kKRow + h * 16;
     floatx4 c0[5], c1[5];
+    const floatx4 cmask = premask_tile4(h);                    // tokens 77..79: -inf from the start of their MFMA chain
 #pragma unroll
     for (int mt = 0; mt < 5; ++mt) {
-        c0[mt] = floatx4{0, 0, 0, 0};
-        c1[mt] = floatx4{0, 0, 0, 0};
+        c0[mt] = mt == 4 ? cmask : floatx4{0, 0, 0, 0};
+        c1[mt] = mt == 4 ? cmask : floatx4{0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const half8 a = *reinterpret_cast<const half8*>(a_rd + mt * 16 * S::kKRow + ks * 64);
@@ -237,15 +192,15 @@ __global__ __launch_bounds__(256, 2) void attend_kernel(const AttendLaunch L)
     half2v ph[2][kSlots16 / 2];                              // packed 16-bit pairs: fp16 values, or bf16 bit patterns
     if constexpr (IN::kBf16) {
         float2v pf[kSlots16 / 2];
-        softmax20_probs_bf16(c0, L.scale, h, pf);
+        softmax20_probs_bf16<true>(c0, L.scale, h, pf);
 #pragma unroll
         for (int i = 0; i < kSlots16 / 2; ++i) ph[0][i] = __builtin_bit_cast(half2v, pack_bf16_exact(pf[i]));
-        softmax20_probs_bf16(c1, L.scale, h, pf);
+        softmax20_probs_bf16<true>(c1, L.scale, h, pf);
 #pragma unroll
         for (int i = 0; i < kSlots16 / 2; ++i) ph[1][i] = __builtin_bit_cast(half2v, pack_bf16_exact(pf[i]));
     } else {
-        softmax20_probs<FAST_EXP>(c0, L.scale, L.round_logits, h, ph[0]);
-        softmax20_probs<FAST_EXP>(c1, L.scale, L.round_logits, h, ph[1]);
+        softmax20_probs<FAST_EXP, true>(c0, L.scale, L.round_logits, h, ph[0]);
+        softmax20_probs<FAST_EXP, true>(c1, L.scale, L.round_logits, h, ph[1]);
     }
 
     // ---- tap: probabilities of the kept heads -> LDS tile [token][pixel] ------------------------------------------

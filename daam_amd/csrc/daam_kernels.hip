@@ -551,19 +551,24 @@ hipError_t launch_clock_monitor(unsigned long long* samples, int n_samples, int 
 // per flush against 435 us when the small kernels' workgroups are resident first and the large grid fills in around them).  One
 // wave on the caller's stream, ahead of the large kernel: wait until the side kernels' workgroups have counted themselves in
 // (TapLaunch::started), or for `timeout_us` -- it holds no LDS and one wave slot, so it can never keep them from starting.
-__global__ __launch_bounds__(64) void start_gate_kernel(const unsigned* counter, unsigned target, int timeout_us)
+// A gate that runs into its timeout (the auxiliary streams did NOT run beside the caller's: e.g. mapped onto one hardware queue)
+// says so in `timeouts` (pinned host memory, device-mapped): the host then stops using the gate for the context.
+__global__ __launch_bounds__(64) void start_gate_kernel(const unsigned* counter, unsigned target, int timeout_us, unsigned* timeouts)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();                 // 100 MHz
     const unsigned long long limit = (unsigned long long)timeout_us * 100ull;
     while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        if (__builtin_amdgcn_s_memrealtime() - t0 > limit) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit) {
+            if (timeouts && threadIdx.x == 0) __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
         __builtin_amdgcn_s_sleep(4);
     }
 }
 
-hipError_t launch_start_gate(const unsigned* counter, unsigned target, int timeout_us, hipStream_t stream)
+hipError_t launch_start_gate(const unsigned* counter, unsigned target, int timeout_us, unsigned* timeouts, hipStream_t stream)
 {
-    hipLaunchKernelGGL(start_gate_kernel, dim3(1), dim3(64), 0, stream, counter, target, timeout_us);
+    hipLaunchKernelGGL(start_gate_kernel, dim3(1), dim3(64), 0, stream, counter, target, timeout_us, timeouts);
     return hipGetLastError();
 }
 

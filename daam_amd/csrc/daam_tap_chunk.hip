@@ -24,6 +24,9 @@
 // Debug aid (tools/exp/chunk_timeline.py; build with -DDAAM_CHUNK_TIMING): per-workgroup stamps -- 100 MHz reference counter at the start,
 // at the first step, after the last step and at the end; shader cycles wave 0 spent in the per-sub-step DMA wait + barrier and in the
 // whole loop; head_dim; HW_ID.
+#ifndef DAAM_CHUNK_PRIO
+#define DAAM_CHUNK_PRIO 0
+#endif
 #ifdef DAAM_CHUNK_TIMING
 __device__ unsigned long long daam_chunk_dbg[4096][8];
 #define DAAM_CT(i, v) do { if (threadIdx.x == 0 && wg < 4096) daam_chunk_dbg[wg][i] = (v); } while (0)
@@ -52,7 +55,7 @@ __device__ __forceinline__ constexpr int ck_swz(int row, int chunk) { return ((c
 // scratch against 125 and none; hipcc turns the two `if`s below into eight v_cndmask each either way.)
 template <typename IN, bool FIRST>
 __device__ __forceinline__ void chunk_mfma(const unsigned char* kb, const unsigned char* qtile, int f_rd, bool partial, int vc, int h,
-                                           floatx4 (&c0)[5], floatx4 (&c1)[5])
+                                           floatx4 (&c0)[5], floatx4 (&c1)[5], const floatx4& cmask)
 {
     const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     half8 q00 = *reinterpret_cast<const half8*>(qtile + f_rd);
@@ -61,9 +64,9 @@ __device__ __forceinline__ void chunk_mfma(const unsigned char* kb, const unsign
 #pragma unroll
     for (int mt = 0; mt < 5; ++mt) {
         const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kCkRow + f_rd);
-        if constexpr (FIRST) {
-            c0[mt] = IN::mfma(a0, q00, floatx4{0, 0, 0, 0});
-            c1[mt] = IN::mfma(a0, q10, floatx4{0, 0, 0, 0});
+        if constexpr (FIRST) {                                             // tokens 77..79 (tile 4): -inf from the start of their chain
+            c0[mt] = IN::mfma(a0, q00, mt == 4 ? cmask : floatx4{0, 0, 0, 0});
+            c1[mt] = IN::mfma(a0, q10, mt == 4 ? cmask : floatx4{0, 0, 0, 0});
         } else {
             c0[mt] = IN::mfma(a0, q00, c0[mt]);
             c1[mt] = IN::mfma(a0, q10, c1[mt]);
@@ -169,6 +172,15 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     const int n_ch = __builtin_amdgcn_readfirstlane((d + 63) >> 6);
     const int vc = __builtin_amdgcn_readfirstlane((d - 64 * (n_ch - 1)) >> 3);
     const bool last_partial = vc < 8;
+#if DAAM_CHUNK_PRIO
+    // Issue priority for the workgroups with the LONGEST dependent chains.  A launch that mixes head dims (SD-v1.5) is as long as its
+    // head_dim-160 workgroups: 50 steps x 3 sub-steps, two of them with a fully exposed DMA wait, and between the waits their waves
+    // queue for the SIMD behind three waves of head_dim-40 workgroups that have a 50-step chain of ONE sub-step each
+    // (tools/exp/chunk_timeline.py: loops of 382 / 297 / 130-187 us for head_dim 160 / 80 / 40 in a 449 us launch).  The light
+    // workgroups lose nothing they need -- the SIMD is busy either way -- the heavy ones stop waiting for it.
+    if (n_ch >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (n_ch == 2) __builtin_amdgcn_s_setprio(2);
+#endif
 
     // operand reads: row l&15 of a 16-row tile, piece 4 ks + (l >> 4); the same offset serves K (A) and Q (B)
     const int f_rd = j * kCkRow + ck_swz(j, h);               // k-step 1: ^ 64
@@ -237,6 +249,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     //   sub-step u - 1, whose K buffer is the one the next fetch overwrites); operand reads + MFMAs; then the DMAs of sub-step
     //   u + 1 (into the other K buffer and into this wave's own Q tile, whose reads the MFMAs have consumed).  After a layer's
     //   last chunk the softmax of the two pixel groups runs with those DMAs in flight.
+    const floatx4 cmask = premask_tile4(h);
     dma(0, 0, 0);
     int buf = 0;
 #ifdef DAAM_CHUNK_TIMING
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         DAAM_CW1();
-        chunk_mfma<IN, true>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && n_ch == 1, vc, h, c0, c1);
+        chunk_mfma<IN, true>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && n_ch == 1, vc, h, c0, c1, cmask);
         buf ^= 1;
         if (n_ch > 1) dma(s, 1, buf); else dma(s_next, 0, buf);
         for (int c = 1; c < n_ch; ++c) {
@@ -264,16 +277,16 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             DAAM_CW1();
-            chunk_mfma<IN, false>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && c == n_ch - 1, vc, h, c0, c1);
+            chunk_mfma<IN, false>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && c == n_ch - 1, vc, h, c0, c1, cmask);
             buf ^= 1;
             if (c + 1 < n_ch) dma(s, c + 1, buf); else dma(s_next, 0, buf);
         }
         if constexpr (IN::kBf16) {
-            softmax20_accumulate_bf16<ACC_T>(c0, lay, h, run0);
-            softmax20_accumulate_bf16<ACC_T>(c1, lay, h, run1);
+            softmax20_accumulate_bf16<ACC_T, true>(c0, lay, h, run0);
+            softmax20_accumulate_bf16<ACC_T, true>(c1, lay, h, run1);
         } else {
-            softmax20_accumulate<ACC_T, FAST_EXP>(c0, lay, h, run0);
-            softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
+            softmax20_accumulate<ACC_T, FAST_EXP, true>(c0, lay, h, run0);
+            softmax20_accumulate<ACC_T, FAST_EXP, true>(c1, lay, h, run1);
         }
     }
 #ifdef DAAM_CHUNK_TIMING

@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     const unsigned q_touch = (unsigned)__builtin_amdgcn_readfirstlane(
         (int)((q_off + (int64_t)min(p0 + wave * 32, lay.hw - 1) * lay.q_sp) * 2));
 #endif
+    const floatx4 cmask = premask_tile4(h);
     // one denoising step: logits of step s from the K and Q tiles in LDS, then the fetches of the next step (head_dim 64: by DMA
     // into the other K buffer / this wave's own Q tile, whose reads are behind it; head_dim < 64: step s + 1 from the staging
     // registers into LDS and the request for step s + 2), softmax + accumulate of the two pixel groups
@@ -294,8 +295,8 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         for (int mt = 0; mt < 5; ++mt) {
             const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kTapRow + f_rd);
             const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kTapRow + (f_rd ^ 64));
-            c0[mt] = IN::mfma(a0, q00, floatx4{0, 0, 0, 0});
-            c1[mt] = IN::mfma(a0, q10, floatx4{0, 0, 0, 0});
+            c0[mt] = IN::mfma(a0, q00, mt == 4 ? cmask : floatx4{0, 0, 0, 0});     // tokens 77..79: -inf from the start of their chain
+            c1[mt] = IN::mfma(a0, q10, mt == 4 ? cmask : floatx4{0, 0, 0, 0});
             c0[mt] = IN::mfma(a1, q01, c0[mt]);
             c1[mt] = IN::mfma(a1, q11, c1[mt]);
         }
@@ -332,11 +333,11 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         issue_q(min(s + 1, n_steps - 1));
 #endif
         if constexpr (IN::kBf16) {
-            softmax20_accumulate_bf16<ACC_T>(c0, lay, h, run0);
-            softmax20_accumulate_bf16<ACC_T>(c1, lay, h, run1);
+            softmax20_accumulate_bf16<ACC_T, true>(c0, lay, h, run0);
+            softmax20_accumulate_bf16<ACC_T, true>(c1, lay, h, run1);
         } else {
-            softmax20_accumulate<ACC_T, FAST_EXP>(c0, lay, h, run0);
-            softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
+            softmax20_accumulate<ACC_T, FAST_EXP, true>(c0, lay, h, run0);
+            softmax20_accumulate<ACC_T, FAST_EXP, true>(c1, lay, h, run1);
         }
 #if DAAM_TAP_DMA
         if constexpr (FULL64) {

@@ -167,14 +167,15 @@ __global__ __launch_bounds__(256, (KS > 3 ? 1 : 2)) void tap_wide_kernel(const T
 
     issue(0);
     commit(0);
+    const floatx4 cmask = premask_tile4(h);
     for (int s = 0; s < n_steps; ++s) {
         __syncthreads();
         const unsigned char* kb = kbuf + (s & 1) * S::kKBuf + f_rd;
         floatx4 c0[5], c1[5];
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
-            c0[mt] = floatx4{0, 0, 0, 0};
-            c1[mt] = floatx4{0, 0, 0, 0};
+            c0[mt] = mt == 4 ? cmask : floatx4{0, 0, 0, 0};     // tokens 77..79: -inf from the start of their MFMA chain
+            c1[mt] = mt == 4 ? cmask : floatx4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(256, (KS > 3 ? 1 : 2)) void tap_wide_kernel(const T
             }
         }
         issue(min(s + 1, n_steps - 1));                       // branch-free: the last step re-fetches itself
-        softmax20_accumulate<ACC_T, FAST_EXP>(c0, lay, h, run0);
-        softmax20_accumulate<ACC_T, FAST_EXP>(c1, lay, h, run1);
+        softmax20_accumulate<ACC_T, FAST_EXP, true>(c0, lay, h, run0);
+        softmax20_accumulate<ACC_T, FAST_EXP, true>(c1, lay, h, run1);
         commit((s + 1) & 1);
     }
     __syncthreads();                                          // all operand reads done before the staging tile reuses the space

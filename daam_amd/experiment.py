@@ -109,6 +109,10 @@ class GenerationExperiment:
         (self.path / self.subtype / 'generation.pt').unlink(missing_ok=True)
 
     def save(self, path: Union[str, Path, None] = None, heat_maps: bool = True, tokenizer=None):
+        """Reference layout on disk (experiment.py:303-344).  One-directional compatibility: ``load`` reads checkpoints pickled by
+        the reference (``daam.experiment.GenerationExperiment`` resolves to this class), but ``generation.pt`` written HERE names
+        ``daam_amd.experiment.GenerationExperiment`` -- the unmodified reference cannot unpickle it without this package importable
+        (every other file of the directory -- prompt.txt, seed.txt, the PNGs, annotations.json -- is the reference's own format)."""
         root = self.path if path is None else Path(path) / self.id
         tokenizer = self.tokenizer if tokenizer is None else tokenizer
         sub = root / self.subtype

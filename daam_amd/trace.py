@@ -37,7 +37,8 @@ def _default_defer() -> int:
 
 def _default_defer_bytes(pipeline=None) -> int:
     """Bytes of recorded Q / K a trace may keep alive between tap launches: ``$DAAM_DEFER_BYTES``, else 40 % of the
-    device memory that is free when the trace is set up (never less than 1 GiB; 32 GiB when the device cannot be asked).
+    device memory that is free when the trace is set up (never less than 1 GiB, never more than 128 GiB; 32 GiB when the device
+    cannot be asked).
     An MI355X has 288 GB: an SDXL-1024 generation holds 19.4 GB for its one launch, and SDXL at 2048 x 2048 (1.55 GB per
     denoising step, both CFG halves of every Q) gets the 64 steps a launch can take -- 100 steps = 2 launches, each
     re-reading the 0.88 GB of running sums once, instead of the 5 a fixed 32 GiB forced."""
@@ -54,7 +55,9 @@ def _default_defer_bytes(pipeline=None) -> int:
             free, _ = torch.cuda.mem_get_info(dev)
             # what torch's caching allocator holds but has not handed out is as good as free for the Q / K to come
             free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-            budget = max(int(free * 0.4), 1 << 30)
+            # absolute ceiling 128 GiB: enough for the 64 steps one launch takes at SDXL-2048 (99 GB), and it bounds what several
+            # traces that each see the same free memory (ranks sharing a device) can pin between them
+            budget = min(max(int(free * 0.4), 1 << 30), 128 << 30)
     except Exception:                                   # no parameters / no device yet: keep the default
         pass
     return budget

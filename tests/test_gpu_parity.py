@@ -109,11 +109,12 @@ def test_tap_qk_vs_oracle(shape, mode, defer):
 
 @pytest.mark.parametrize('d', [64, 40, 80])
 def test_tap_wide_logit_spread(d):
-    """The fast softmax takes token 0's logit as its reference point and falls back to the true row maximum
-    when a logit exceeds it by more than ~69 (1/sum would go subnormal, then the exponentials overflow): rows
-    with a 36 / 72 / 96 / 192 spread above token 0, next to ordinary rows, still match the oracle."""
+    """The fast softmax takes the exponentials of the logits themselves (no reference point, round 4) and falls back to the true row
+    maximum when a pixel's sum leaves [2^-100, 2^100] (1/sum would leave the normal f32 range; further out the exponentials overflow
+    / vanish): rows whose logits reach +-36 / 48 / 72 / 96 / 192 next to ordinary rows, and a step whose logits are ALL around -48 /
+    -96 / -192 (sums of 2^-63 -- fine -- and of 2^-132 / 0 -- redone), still match the oracle."""
     rng = np.random.default_rng(5)
-    heads, side, steps = 2, 16, 3
+    heads, side, steps = 2, 16, 4
     hw = side * side
     qs, ks = [], []
     for s in range(steps):
@@ -124,6 +125,8 @@ def test_tap_wide_logit_spread(d):
         q[:, ::3] = np.float16(2.0 * np.sqrt(g))
         k[:, 0] = np.float16(-3.0 * np.sqrt(g))                    # token 0 far BELOW the others on those rows
         k[:, 5] = np.float16(3.0 * np.sqrt(g))
+        if s == 3:                                                 # every token far below zero: the sum underflows on the wide rows
+            k[:] = np.float16(-3.0 * np.sqrt(g)) + (k * np.float16(0.02)).astype(np.float16)
         q[:, 1::3, 1] *= np.float16(2.0)                           # second head: other rows get a 2x wider spread
         q[:, 2::9] = np.float16(0.75 * np.sqrt(g))                 # spread 36: below the switch
         q[:, 5::9] = np.float16(1.5 * np.sqrt(g))                  # spread 72: just above it, exponentials still finite
