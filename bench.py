@@ -124,7 +124,8 @@ def one_generation(eng, calls, denoise_steps):
     for t in range(denoise_steps):
         for a in calls[t % n]:
             tap(*a)
-    eng.flush()
+    # compute_global_heat_map() as daam_amd.trace calls it: the engine announces the output, launches the recorded taps (whose
+    # table-upload kernel clears it) and runs the finalize -- no separate flush in front
     return eng.global_heat_map()
 
 

@@ -15,7 +15,7 @@
 
 namespace daam {
 
-// debug aid (tools/fin_timing.py; build with -DDAAM_FIN_TIMING): per-workgroup phase timestamps of the x2 MFMA kernel
+// debug aid (tools/exp/fin_timing.py; build with -DDAAM_FIN_TIMING): per-workgroup phase timestamps of the x2 MFMA kernel
 #ifdef DAAM_FIN_TIMING
 __device__ unsigned long long daam_fin_dbg[1024][4];
 #define DAAM_FT(i) do { if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1024) \

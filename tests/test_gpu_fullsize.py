@@ -7,7 +7,7 @@ Tolerances (fp16 pipeline, fp16 sums = the reference's arithmetic, heatmap.py:15
 at the same points (fp16 logits, f32 softmax, fp16 probabilities, fp16 add); they differ in the f32 summation order of
 q.k, which moves a logit across an fp16 rounding boundary now and then (0.02 - 0.06 % of the elements).  One ulp of a logit
 of magnitude 8 .. 32 is 2^-7 .. 2^-6, so that step's probability -- and, when the flipped logit is the row's dominant one,
-every probability of the row -- changes by up to e^(2^-6) - 1 = 1.6 % (measured with tools/debug_ulps.py: the compensated
+every probability of the row -- changes by up to e^(2^-6) - 1 = 1.6 % (measured with tools/exp/debug_ulps.py: the compensated
 and the fast softmax, immediate and deferred launches all show the same elements).  Any two correct implementations of
 the reference's arithmetic (rocBLAS vs MKL GEMM order) differ like this.  Hence:
   * running sums, every element: |diff| <= 2^-6 |value| + 2 ulp(value);  whole key: within 1 ulp of its largest sum;

@@ -1,6 +1,6 @@
 """Debug: extraction time of a 10-step SDXL-1024 generation per pipeline dtype (fp16 = MFMA kernels, bf16 = any-shape kernels)."""
 import sys, time, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from daam_amd.engine import HeatMapEngine
 dev = torch.device('cuda', 0)

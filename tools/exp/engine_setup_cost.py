@@ -1,6 +1,6 @@
 """Debug: what a fresh HeatMapEngine (a new trace) costs per generation compared with a reused one (MI355X)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from daam_amd.engine import HeatMapEngine

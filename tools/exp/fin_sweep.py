@@ -1,6 +1,6 @@
 """Debug: finalize time (HIP events around the finalize kernels, no clock monitor) for the bench workload."""
 import ctypes, os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from daam_amd.engine import HeatMapEngine

@@ -1,8 +1,8 @@
 """Debug: per-workgroup phase timestamps of finalize_up32_mfma_kernel.  Needs a library built with
 -DDAAM_FIN_TIMING:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DDAAM_FIN_TIMING daam_amd/csrc/*.hip -o X.so;
-DAAM_HIP_LIB=X.so python tools/fin_timing.py"""
+DAAM_HIP_LIB=X.so python tools/exp/fin_timing.py"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from daam_amd.engine import HeatMapEngine

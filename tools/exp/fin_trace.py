@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Timeline of the finalize launches in a rocprofv3 --kernel-trace CSV: start / end of the upload, class kernels of the last
 few compute_global_heat_map calls relative to the upload kernel (which kernel waits for which, how long the gaps are).
-    python tools/fin_trace.py <dir with *_kernel_trace.csv>"""
+    python tools/exp/fin_trace.py <dir with *_kernel_trace.csv>"""
 import csv
 import glob
 import os

@@ -1,6 +1,6 @@
 """Debug: where the host time of one bench generation goes (no device sync inside the loop)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
 from daam_amd.engine import HeatMapEngine
 defer = int(sys.argv[1]) if len(sys.argv) > 1 else 16

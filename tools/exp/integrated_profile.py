@@ -1,6 +1,6 @@
 """Debug: where the integrated-harness overhead of tests/test_gpu_integration.py comes from (MI355X)."""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import torch
 from oracle import fake_diffusers as fd
 import test_gpu_integration as T

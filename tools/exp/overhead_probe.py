@@ -4,7 +4,7 @@ For the plain and the traced arm of the synthetic SDXL-1024 stack: host time to 
 pipe(), no sync), GPU time of the stack (events around pipe()), and for the traced arm the time of flush + finalize.
 Paired, interleaved generations; medians.
 
-    python tools/overhead_probe.py [steps] [reps]
+    python tools/exp/overhead_probe.py [steps] [reps]
 """
 import json
 import os
@@ -14,7 +14,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

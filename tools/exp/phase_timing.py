@@ -1,6 +1,6 @@
 """Debug: per-phase wave latency of the tap kernel (needs tools/libdaam_ablate9.so, built with -DDAAM_ABLATE=9)."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from daam_amd.engine import HeatMapEngine

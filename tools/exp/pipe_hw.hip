@@ -25,7 +25,7 @@
 
 namespace daam {
 
-// debug aid (tools/pipe_timing.py; build with -DDAAM_PIPE_TIMING): per-wave phase timestamps (100 MHz reference counter)
+// debug aid (tools/exp/pipe_timing.py; build with -DDAAM_PIPE_TIMING): per-wave phase timestamps (100 MHz reference counter)
 #ifdef DAAM_PIPE_TIMING
 __device__ unsigned long long daam_pipe_dbg[4096][12];     // [0..5] phase stamps (100 MHz), [6..7] shader-cycle counter around the loop
 #define DAAM_PT(i) do { if ((threadIdx.x & 63) == 0) { const unsigned w_ = (blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 6); \
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // WHEN: workgroups alternate -- even ones before their x2 loop (under the latency of the ring's first planes), odd ones
     // after it -- so that at any time about half of a CU's waves stream same-size planes from HBM (no arithmetic to speak of)
     // while the other half run the issue-bound x2 loop with a SIMD to themselves (measured with every workgroup streaming first:
-    // 15 us in which no x2 plane was computed, tools/pipe_timing.py).
+    // 15 us in which no x2 plane was computed, tools/exp/pipe_timing.py).
     floatx16 accA0 = {0}, accA1 = {0};                         // even planes x output row halves (mt); the pipeline adds to them
     // (workgroups are dispatched breadth-first, one per CU per sweep of 256: consecutive sweeps alternate, so every CU hosts both kinds)
     const bool same_first = (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1) == 0;

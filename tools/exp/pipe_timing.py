@@ -1,8 +1,8 @@
 """Debug: per-wave phase timestamps of finalize_up32_pipe_kernel + HIP-event times of finalize for several key selections.
 Needs a library built with -DDAAM_PIPE_TIMING (daam_amd.build.build_variant(out, ['-DDAAM_PIPE_TIMING']));
-    DAAM_HIP_LIB=X.so python tools/pipe_timing.py"""
+    DAAM_HIP_LIB=X.so python tools/exp/pipe_timing.py"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from daam_amd.engine import HeatMapEngine

@@ -1,6 +1,6 @@
 """Debug: wall time of the first 40 generations of the bench workload, one sync each (context creation, clock ramp)."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from daam_amd.engine import HeatMapEngine
 dev = torch.device('cuda', 0)

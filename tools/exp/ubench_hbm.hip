@@ -1,7 +1,7 @@
 // HBM read-bandwidth probes on gfx950 (tools only): what can a read-dominated kernel reach, and how
 // much does the tap kernel's access pattern (64-byte pieces of 128-byte rows at a 2560-byte stride,
 // one tensor per step) cost against a plain stream?
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_hbm.hip -o tools/ubench_hbm && tools/ubench_hbm
+//   hipcc --offload-arch=gfx950 -O3 tools/exp/ubench_hbm.hip -o tools/exp/ubench_hbm && tools/exp/ubench_hbm
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,5 +1,5 @@
 // Do MFMA and VALU work of DIFFERENT waves on one SIMD overlap on gfx950?  (tools only)
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_overlap.hip -o tools/ubench_overlap && tools/ubench_overlap
+//   hipcc --offload-arch=gfx950 -O3 tools/exp/ubench_overlap.hip -o tools/exp/ubench_overlap && tools/exp/ubench_overlap
 // One workgroup of 8 waves per CU (waves w and w+4 share SIMD w): mode 0 = waves 0-3 run an MFMA loop, 4-7 idle;
 // mode 1 = waves 4-7 run a VALU loop, 0-3 idle; mode 2 = both.  Overlap => t(2) ~ max(t0, t1); none => t0 + t1.
 #include <hip/hip_runtime.h>

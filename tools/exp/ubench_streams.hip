@@ -1,5 +1,5 @@
 // Do two small kernels on two non-blocking streams overlap on this box?  (tools only)
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_streams.hip -o tools/ubench_streams && tools/ubench_streams
+//   hipcc --offload-arch=gfx950 -O3 tools/exp/ubench_streams.hip -o tools/exp/ubench_streams && tools/exp/ubench_streams
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
