@@ -295,17 +295,28 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         for (int mt = 0; mt < 5; ++mt) {
             const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kTapRow + f_rd);
             const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kTapRow + (f_rd ^ 64));
+#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 3            // timing experiment 3: no MFMAs (and no operand reads): what do they cost?
+            c0[mt] = mt == 4 ? cmask : floatx4{(float)s, 1.f, 2.f, 3.f};
+            c1[mt] = mt == 4 ? cmask : floatx4{3.f, 2.f, 1.f, (float)s};
+            (void)a0; (void)a1; (void)q00; (void)q01; (void)q10; (void)q11;
+#else
             c0[mt] = IN::mfma(a0, q00, mt == 4 ? cmask : floatx4{0, 0, 0, 0});     // tokens 77..79: -inf from the start of their chain
             c1[mt] = IN::mfma(a0, q10, mt == 4 ? cmask : floatx4{0, 0, 0, 0});
             c0[mt] = IN::mfma(a1, q01, c0[mt]);
             c1[mt] = IN::mfma(a1, q11, c1[mt]);
+#endif
         }
 #if DAAM_TAP_DMA
         if constexpr (FULL64) {
             // the K buffer of step s + 1 was last read in step s - 1 (every wave is past this step's barrier); this wave's Q
             // tile was read by the operand loads above, which the MFMAs have consumed
+#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 2            // timing experiment 2: every step re-reads step 0 (cache-resident)
+            dma_k(0, (s + 1) & 1);
+            dma_q(0);
+#else
             dma_k(min(s + 1, n_steps - 1), (s + 1) & 1);
             dma_q(min(s + 1, n_steps - 1));
+#endif
 #if DAAM_TAP_TOUCH
             {
                 // one dword of the Q rows / the K tensor this wave fetches DAAM_TAP_TOUCH steps later, by DMA into a scratch corner
@@ -331,6 +342,17 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
 #else
         issue_k(min(s + 1, n_steps - 1));                     // branch-free: the last step re-fetches itself
         issue_q(min(s + 1, n_steps - 1));
+#endif
+#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 5            // timing experiment 5: no softmax (the MFMA results are only folded into the sums)
+        if constexpr (sizeof(ACC_T) == 2 && !IN::kBf16) {
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                run0[2 * mt] += __builtin_convertvector(float2v{c0[mt][0], c0[mt][1]}, half2v);
+                run0[2 * mt + 1] += __builtin_convertvector(float2v{c0[mt][2], c0[mt][3]}, half2v);
+                run1[2 * mt] += __builtin_convertvector(float2v{c1[mt][0], c1[mt][1]}, half2v);
+                run1[2 * mt + 1] += __builtin_convertvector(float2v{c1[mt][2], c1[mt][3]}, half2v);
+            }
+        } else
 #endif
         if constexpr (IN::kBf16) {
             softmax20_accumulate_bf16<ACC_T, true>(c0, lay, h, run0);
