@@ -39,6 +39,14 @@
 #ifndef DAAM_TAP_DMA
 #define DAAM_TAP_DMA 1
 #endif
+// the next step's DMAs ahead of this step's MFMAs instead of behind them (K: right after the barrier, its other buffer is free; Q: once
+// the wave's four operand reads have returned) -- ~0.3 us more for a fetch to land.  Round 4: the launch sits on the floor of its data
+// path (the same launch WITHOUT softmax and MFMAs takes as long, LABNOTES R4.6), and this buys 0.5-0.8 % on it; -DDAAM_TAP_EARLY_DMA=0
+// for A/B runs.  (Tried on top, measured and removed: half of every second step's Q tile through a register set requested two steps
+// ahead -- the bare data path 3-4 % faster, the whole kernel 1 % slower: data path, issue and the power cap meet at this point.)
+#ifndef DAAM_TAP_EARLY_DMA
+#define DAAM_TAP_EARLY_DMA 1
+#endif
 
 // TLB-warming touch (experiment, off by default; -DDAAM_TAP_TOUCH=N): a wave reads ONE dword of the Q rows and of the K tensor it
 // will fetch N steps later.  Why: the launch time depends on the FOOTPRINT of the recorded Q / K, not only on the bytes moved
@@ -287,15 +295,26 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         __syncthreads();
 #endif
         const unsigned char* kb = kbuf + (s & 1) * kTapKBuf;
+#if DAAM_TAP_DMA && DAAM_TAP_EARLY_DMA
+        // the K buffer of step s + 1 was last read in step s - 1 and every wave is past this step's barrier: its DMAs go out first
+        if constexpr (FULL64) dma_k(min(s + 1, n_steps - 1), (s + 1) & 1);
+#endif
         const half8 q00 = *reinterpret_cast<const half8*>(qtile + f_rd), q01 = *reinterpret_cast<const half8*>(qtile + (f_rd ^ 64));
         const half8 q10 = *reinterpret_cast<const half8*>(qtile + 16 * kTapRow + f_rd);
         const half8 q11 = *reinterpret_cast<const half8*>(qtile + 16 * kTapRow + (f_rd ^ 64));
+#if DAAM_TAP_DMA && DAAM_TAP_EARLY_DMA
+        if constexpr (FULL64) {
+            // this wave's Q tile is free once its four operand reads have returned: the next step's rows are requested BEFORE the MFMAs
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_q(min(s + 1, n_steps - 1));
+        }
+#endif
         floatx4 c0[5], c1[5];
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
             const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kTapRow + f_rd);
             const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kTapRow + (f_rd ^ 64));
-#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 3            // timing experiment 3: no MFMAs (and no operand reads): what do they cost?
+#if defined(DAAM_TAP_ABLATE) && (DAAM_TAP_ABLATE == 3 || DAAM_TAP_ABLATE == 6)   // timing experiment 3: no MFMAs (and no operand reads); 6 = 3 + 5: the bare data path
             c0[mt] = mt == 4 ? cmask : floatx4{(float)s, 1.f, 2.f, 3.f};
             c1[mt] = mt == 4 ? cmask : floatx4{3.f, 2.f, 1.f, (float)s};
             (void)a0; (void)a1; (void)q00; (void)q01; (void)q10; (void)q11;
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
 #if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 2            // timing experiment 2: every step re-reads step 0 (cache-resident)
             dma_k(0, (s + 1) & 1);
             dma_q(0);
-#else
+#elif !DAAM_TAP_EARLY_DMA
             dma_k(min(s + 1, n_steps - 1), (s + 1) & 1);
             dma_q(min(s + 1, n_steps - 1));
 #endif
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         issue_k(min(s + 1, n_steps - 1));                     // branch-free: the last step re-fetches itself
         issue_q(min(s + 1, n_steps - 1));
 #endif
-#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 5            // timing experiment 5: no softmax (the MFMA results are only folded into the sums)
+#if defined(DAAM_TAP_ABLATE) && (DAAM_TAP_ABLATE == 5 || DAAM_TAP_ABLATE == 6)   // timing experiment 5: no softmax (the MFMA results are only folded into the sums)
         if constexpr (sizeof(ACC_T) == 2 && !IN::kBf16) {
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
@@ -394,6 +413,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     commit_q();
 #endif
     for (int s = 0; s < n_steps; ++s) step(s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of the last (redundant) fetches is in flight any more
     __syncthreads();                                          // all K reads done before the staging tile reuses the space
 
     // ---- write back: registers -> LDS [token][pixel] -> 16-byte row pieces -------------------
