@@ -14,18 +14,20 @@ if [ "${SKIP_TESTS:-0}" != 1 ]; then
   say "pytest -m gpu: $(tail -1 "$out/gpu_tests.txt")"
   grep -E "^FAILED|^ERROR" "$out/gpu_tests.txt" | head -20
 fi
-for wl in sdxl1024 sd15 sdxl2048; do
+[ "${SKIP_PROFILE:-0}" = 1 ] || for wl in sdxl1024 sd15 sdxl2048; do
   ds=50; [ $wl = sdxl2048 ] && ds=100
   dfr=$ds; [ $wl = sdxl2048 ] && dfr=64
   timeout 500 bash tools/profile_round.sh $TAG $wl $ds $dfr 20 4 > "$out/profile_$wl.log" 2>&1
   say "profile $wl: $(grep -c wrote "$out/profile_$wl.log") files"
 done
+# the bench lines read the counters measured minutes ago on this box (bench.py takes profiles/<tag>_counters.json when the kernels match)
+[ -f gpurun_out/profiles_$TAG/${TAG}_counters.json ] && cp gpurun_out/profiles_$TAG/${TAG}_counters.json profiles/
 timeout 600 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.log"
 say "bench default: $(python -c "import json;r=json.loads([l for l in open('$out/bench_default.json') if l.startswith('{')][0]);print(r['value'], r['roofline']['ms_per_launch'], r['roofline']['frac'], r['roofline'].get('traffic_over_algorithmic'), r['roofline_finalize']['ms_per_launch'], r['cpu_baseline']['value'])")"
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_form.json" 2> "$out/bench_driver_form.log"
 say "bench driver form: $(python -c "import json;r=json.loads([l for l in open('$out/bench_driver_form.json') if l.startswith('{')][0]);print(r['value'], r['roofline']['ms_per_launch'], r['roofline']['frac'])")"
 # power / clock while the tap launches run back to back: every byte from HBM (one step set per step) and a pool of 12 (re-used from the Infinity Cache)
-for pool in 0 12; do
+[ "${SKIP_POWER:-0}" = 1 ] || for pool in 0 12; do
   O=$out/power_pool$pool; mkdir -p $O
   sample() { rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | sed -E 's/^GPU\[0\][[:space:]]*:[[:space:]]*//' | tr '\n' ';'; echo; }
   echo "# python bench.py --no-baselines --no-integrated --no-other-configs --no-pmc --steps 3000 --warmup 10 --pool $pool   (pool 0 = one distinct step set per denoising step)" > $O/power_sclk.txt
