@@ -742,11 +742,12 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
                          mfma_insts_per_simd=n_mfma, mfma_pipe_cycles_each=32.6,
                          model='floor = max(MFMA count x 32.6 cycles of matrix pipe, VALU-busy cycles) per SIMD at the clock sampled in this run; '
                                'the x2 bicubic of an fp16 plane is 10 MFMA 32x32x16 per half plane (DESIGN.md 3.3): the op is bound by the matrix '
-                               'pipe, not by HBM',
+                               'pipe, not by HBM; frac = that floor / the whole call (the loop is ~60 % of it)',
                          matrix_pipe_floor_ms=round(pipe_ms, 4), valu_floor_ms=round(valu_ms, 4),
                          floor_ms=round(fl, 4), frac=round(fl / fin_ms, 4), source=prof_note, counters_measured_in_run=False)
     out['fin_ms'] = fin_ms
-    out['roofline_finalize'] = dict(bound='hbm', bound_in_fact='matrix-pipe (see roofline_finalize_issue)' if name != 'sdxl2048' else 'hbm', kernel=fin_kernel, achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
+    out['roofline_finalize'] = dict(bound='hbm', bound_in_fact=('matrix pipe for the x2 loop (~60 % of the kernel\'s span, running at ~0.8 of that pipe: DESIGN.md 3.3) + ring prefill, same-size keys, '
+                                                   'reduction / atomics around it; roofline_finalize_issue has the floor') if name != 'sdxl2048' else 'hbm', kernel=fin_kernel, achieved=round(fin_gbs, 1), peak=HBM_PEAK_GBS,
                                     unit='GB/s', frac=round(fin_gbs / HBM_PEAK_GBS, 4), bytes_per_launch=int(fin_bytes),
                                     ms_per_launch=round(fin_ms, 4), traffic=rec.get('finalize_bytes_per_launch') if rec else None,
                                     traffic_measured_in_run=False)
