@@ -24,9 +24,6 @@
 // Debug aid (tools/exp/chunk_timeline.py; build with -DDAAM_CHUNK_TIMING): per-workgroup stamps -- 100 MHz reference counter at the start,
 // at the first step, after the last step and at the end; shader cycles wave 0 spent in the per-sub-step DMA wait + barrier and in the
 // whole loop; head_dim; HW_ID.
-#ifndef DAAM_CHUNK_PRIO
-#define DAAM_CHUNK_PRIO 0
-#endif
 #ifdef DAAM_CHUNK_TIMING
 __device__ unsigned long long daam_chunk_dbg[4096][8];
 #define DAAM_CT(i, v) do { if (threadIdx.x == 0 && wg < 4096) daam_chunk_dbg[wg][i] = (v); } while (0)
@@ -172,15 +169,6 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     const int n_ch = __builtin_amdgcn_readfirstlane((d + 63) >> 6);
     const int vc = __builtin_amdgcn_readfirstlane((d - 64 * (n_ch - 1)) >> 3);
     const bool last_partial = vc < 8;
-#if DAAM_CHUNK_PRIO
-    // Issue priority for the workgroups with the LONGEST dependent chains.  A launch that mixes head dims (SD-v1.5) is as long as its
-    // head_dim-160 workgroups: 50 steps x 3 sub-steps, two of them with a fully exposed DMA wait, and between the waits their waves
-    // queue for the SIMD behind three waves of head_dim-40 workgroups that have a 50-step chain of ONE sub-step each
-    // (tools/exp/chunk_timeline.py: loops of 382 / 297 / 130-187 us for head_dim 160 / 80 / 40 in a 449 us launch).  The light
-    // workgroups lose nothing they need -- the SIMD is busy either way -- the heavy ones stop waiting for it.
-    if (n_ch >= 3) __builtin_amdgcn_s_setprio(3);
-    else if (n_ch == 2) __builtin_amdgcn_s_setprio(2);
-#endif
 
     // operand reads: row l&15 of a 16-row tile, piece 4 ks + (l >> 4); the same offset serves K (A) and Q (B)
     const int f_rd = j * kCkRow + ck_swz(j, h);               // k-step 1: ^ 64
