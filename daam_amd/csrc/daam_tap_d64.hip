@@ -43,7 +43,9 @@
 // the wave's four operand reads have returned) -- ~0.3 us more for a fetch to land.  Round 4: the launch sits on the floor of its data
 // path (the same launch WITHOUT softmax and MFMAs takes as long, LABNOTES R4.6), and this buys 0.5-0.8 % on it; -DDAAM_TAP_EARLY_DMA=0
 // for A/B runs.  (Tried on top, measured and removed: half of every second step's Q tile through a register set requested two steps
-// ahead -- the bare data path 3-4 % faster, the whole kernel 1 % slower: data path, issue and the power cap meet at this point.)
+// ahead -- the bare data path 3-4 % faster, the whole kernel 1 % slower; and FIVE workgroups per CU -- one K buffer + a second, bare,
+// barrier, 27.6 KB of LDS, __launch_bounds__(256, 5) = 96 VGPRs with three spills outside the loop: 25 % more Q bytes in flight and a
+// fifth wave per SIMD, the launch 1 % slower.  Data path, issue and the power cap meet at this point.)
 #ifndef DAAM_TAP_EARLY_DMA
 #define DAAM_TAP_EARLY_DMA 1
 #endif
@@ -295,9 +297,14 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         __syncthreads();
 #endif
         const unsigned char* kb = kbuf + (s & 1) * kTapKBuf;
+#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 2            // timing experiment 2: every step re-reads step 0 (cache-resident)
+        [[maybe_unused]] const int s_fetch = 0;
+#else
+        [[maybe_unused]] const int s_fetch = min(s + 1, n_steps - 1);   // branch-free: the last step re-fetches itself
+#endif
 #if DAAM_TAP_DMA && DAAM_TAP_EARLY_DMA
         // the K buffer of step s + 1 was last read in step s - 1 and every wave is past this step's barrier: its DMAs go out first
-        if constexpr (FULL64) dma_k(min(s + 1, n_steps - 1), (s + 1) & 1);
+        if constexpr (FULL64) dma_k(s_fetch, (s + 1) & 1);
 #endif
         const half8 q00 = *reinterpret_cast<const half8*>(qtile + f_rd), q01 = *reinterpret_cast<const half8*>(qtile + (f_rd ^ 64));
         const half8 q10 = *reinterpret_cast<const half8*>(qtile + 16 * kTapRow + f_rd);
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         if constexpr (FULL64) {
             // this wave's Q tile is free once its four operand reads have returned: the next step's rows are requested BEFORE the MFMAs
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            dma_q(min(s + 1, n_steps - 1));
+            dma_q(s_fetch);
         }
 #endif
         floatx4 c0[5], c1[5];
@@ -329,12 +336,9 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         if constexpr (FULL64) {
             // the K buffer of step s + 1 was last read in step s - 1 (every wave is past this step's barrier); this wave's Q
             // tile was read by the operand loads above, which the MFMAs have consumed
-#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 2            // timing experiment 2: every step re-reads step 0 (cache-resident)
-            dma_k(0, (s + 1) & 1);
-            dma_q(0);
-#elif !DAAM_TAP_EARLY_DMA
-            dma_k(min(s + 1, n_steps - 1), (s + 1) & 1);
-            dma_q(min(s + 1, n_steps - 1));
+#if !DAAM_TAP_EARLY_DMA
+            dma_k(s_fetch, (s + 1) & 1);
+            dma_q(s_fetch);
 #endif
 #if DAAM_TAP_TOUCH
             {
