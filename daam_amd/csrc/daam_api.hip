@@ -1353,9 +1353,11 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         L.max_side = max_side;
         L.mfma_ops = (cls == 1 && mfma_up) ? c->d_up32_ops : nullptr;
         if (cls == 0) {
-            // 154 workgroups per chunk: 4 chunks for the 100 same-size keys of SDXL-1024, up to 16 (2464 workgroups, ~2.4 rounds)
-            // for the 1000 of SDXL-2048 -- a pure HBM stream wants every CU's queues full
-            L.n_chunks = std::max(1, std::min(n, env_chunks ? env_chunks : std::min(16, std::max(4, n / 32))));
+            // 154 workgroups per chunk: 4 chunks for the 100 same-size keys of SDXL-1024, up to 9 (1386 workgroups) for the 1000 of
+            // SDXL-2048.  Round 2 had 16 there; round 4's sweep (tools/exp/fin_chunks_sweep.sh: 4 ... 64 chunks) has its optimum at
+            // 8 - 10 -- the x0.5 class now streams beside this one on a side stream, and every chunk ends in 315 k atomics per
+            // token plane: 0.186 -> 0.159 ms for the SDXL-2048 call (0.59 -> 0.69 of the HBM peak)
+            L.n_chunks = std::max(1, std::min(n, env_chunks ? env_chunks : std::min(9, std::max(4, n / 32))));
         } else if (cls == 3) {
             L.n_chunks = std::max(1, std::min(n, 32));
         } else {
