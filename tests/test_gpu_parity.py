@@ -368,6 +368,55 @@ def test_finalize_prepare_paths(monkeypatch):
     E.release_parked_contexts()
 
 
+def test_raw_abi_strides_past_32_bit_offsets_fall_back():
+    """A raw C-ABI caller whose Q is a view into a large fused buffer (batch stride 2^30 elements = 2 GiB in fp16): the
+    specialised tap kernels address Q / K with 32-bit byte offsets, so such a call must take the any-shape kernel instead of
+    wrapping (round-3 advisor finding) -- same sums as the same data in standard layout, immediate and deferred."""
+    import ctypes
+    from daam_amd import _native as nat
+    heads, side, d, batch = 2, 16, 64, 2
+    hw, c = side * side, heads * d
+    g = torch.Generator(device=DEV).manual_seed(9)
+    q = torch.randn(batch, hw, c, generator=g, device=DEV, dtype=torch.float16)
+    k = torch.randn(batch, 77, c, generator=g, device=DEV, dtype=torch.float16)
+    stride_b = 1 << 30
+    big = torch.zeros(stride_b + hw * c, device=DEV, dtype=torch.float16)          # 2 GiB + one batch element
+    big[:hw * c] = q[0].reshape(-1)
+    big[stride_b:] = q[1].reshape(-1)
+    scale = d ** -0.5
+
+    ref = _engine(n_layers=1, defer_steps=0)
+    ref.tap_qk(0, q, k, heads, scale, 4)
+    want = {key: v.clone() for key, v in ref.items()}
+    ref.close()
+
+    for deferred in (False, True):
+        eng = _engine(n_layers=1, defer_steps=0)
+        eng._require_device(big)                                                   # binds the engine to the device (tap_qk does this)
+        eng._ensure_ctx(torch.float16)
+        eng._ensure_layer(0, heads, side, 4)                                       # kept batch*heads entries = BH - BH/2 = heads
+        eng._touch(0)
+        desc = nat.QKDesc(in_dtype=0, batch=batch, heads=heads, hw=hw, tokens=77, head_dim=d, round_logits=1, scale=float(scale),
+                          q_stride_b=stride_b, q_stride_h=d, q_stride_p=c, k_stride_b=77 * c, k_stride_h=d, k_stride_t=c)
+        if deferred:
+            nat.check(eng.lib.daam_tap_qk_enqueue(eng.ctx, 0, big.data_ptr(), k.data_ptr(), ctypes.byref(desc)))
+            nat.check(eng.lib.daam_tap_flush(eng.ctx, eng.stream))
+        else:
+            nat.check(eng.lib.daam_tap_qk(eng.ctx, 0, big.data_ptr(), k.data_ptr(), ctypes.byref(desc), eng.stream))
+        torch.cuda.synchronize()
+        grid, block, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        nat.check(eng.lib.daam_last_launch(eng.ctx, 0, ctypes.byref(grid), ctypes.byref(block), ctypes.byref(lds)))
+        got = {key: v.clone() for key, v in eng.items()}
+        assert list(got) == list(want)
+        for key in want:
+            a, b = got[key].float(), want[key].float()
+            assert float(b.abs().max()) > 0
+            # another kernel (f32 FMA dot products): the tolerance of the kernel-path tests
+            assert float((a - b).abs().max()) <= 2.0 ** -10 * max(1.0, float(b.max())), (deferred, key)
+        eng.close()
+    del big
+
+
 def test_views_survive_clear_and_next_generation():
     """``all_heat_maps`` hands out views of the live sums; like the reference's tensors (heatmap.py:170-172: clear() drops the
     dict, tensors handed out before live on) they must keep their values through clear() AND through the next
