@@ -222,6 +222,15 @@ struct DaamCtx {
     long long n_flushes = 0;           // tap launches (flushes that launched something) since the context was created
     int profile = 0;
     hipEvent_t prof_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    // daam_profile_enable(ctx, 2): every launch of a kind (0 tap, 1 finalize) gets its own event pair out of a ring, so that a caller
+    // can time the launches of a whole timed region WITHOUT synchronising inside it (daam_profile_history afterwards)
+    static constexpr int kProfHist = 256;
+    std::vector<hipEvent_t> hist_ev[2][2];
+    long long hist_count[2] = {0, 0};
+    hipEvent_t prof_event(int which, int end) {
+        if (profile == 2 && !hist_ev[which][end].empty()) return hist_ev[which][end][(size_t)(hist_count[which] % kProfHist)];
+        return prof_ev[which][end];
+    }
     // shader-clock monitor (daam_clock_monitor_*): one wave on its own stream samples the shader-cycle counter and the
     // 100 MHz reference counter into pinned memory while the kernels under test run
     unsigned long long* clk_host = nullptr;
@@ -437,6 +446,10 @@ int daam_ctx_destroy(DaamCtx* c)
     for (auto& pair : c->prof_ev)
         for (auto& ev : pair)
             if (ev) (void)hipEventDestroy(ev);
+    for (auto& pair : c->hist_ev)
+        for (auto& ring : pair)
+            for (auto ev : ring)
+                if (ev) (void)hipEventDestroy(ev);
     if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
     if (c->d_started) (void)hipFree(c->d_started);
     if (c->gate_timeouts) (void)hipHostFree(c->gate_timeouts);
@@ -975,7 +988,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     for (size_t i = 1; i < prepared.size(); ++i)
         if (prepared[i].L.total_wgs > prepared[main_idx].L.total_wgs) main_idx = i;
     const bool ev_started = c->profile && !rc && !prepared.empty();
-    if (ev_started) (void)hipEventRecord(c->prof_ev[0][0], s);
+    if (ev_started) (void)hipEventRecord(c->prof_event(0, 0), s);
     bool forked = false;
     if (side && !rc) {
         if (hipEventRecord(c->aux_fork, s) != hipSuccess) rc = fail(DAAM_E_STATE, "stream fork failed");
@@ -1037,7 +1050,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     // join (after the main kernel is enqueued): the caller's stream continues when every side kernel is done
     for (int i = 0; i < n_side; ++i)
         if (hipStreamWaitEvent(s, c->aux_join[i], 0) != hipSuccess) rc = rc ? rc : fail(DAAM_E_STATE, "stream join failed");
-    if (c->profile && ev_started) (void)hipEventRecord(c->prof_ev[0][1], s);
+    if (c->profile && ev_started) { (void)hipEventRecord(c->prof_event(0, 1), s); ++c->hist_count[0]; }
     c->last_grid[0] = grid_total;
     c->last_block[0] = 256;
     c->last_flush_kernels = (int)launch_order.size();
@@ -1292,7 +1305,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         hipError_t ze = hipMemsetAsync(out, 0, out_bytes, s);
         if (ze != hipSuccess) return fail((int)ze, "output memset: %s", hipGetErrorString(ze));
     }
-    if (c->profile) (void)hipEventRecord(c->prof_ev[1][0], s);    // timed: what this call launches (table upload + zeroing if needed, class kernels)
+    if (c->profile) (void)hipEventRecord(c->prof_event(1, 0), s);    // timed: what this call launches (table upload + zeroing if needed, class kernels)
     void* zero_ptr = (zero_in_upload && !prepared) ? out : nullptr;
     const size_t zero_n = zero_ptr ? out_bytes : 0;
     const char* tab_dev = nullptr;
@@ -1461,7 +1474,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     for (int i = 0; i < n_side; ++i)
         if (hipStreamWaitEvent(s, c->aux_join[i], 0) != hipSuccess) { release_tab(); return fail(DAAM_E_STATE, "stream join failed"); }
     c->last_fin_side = n_side;
-    if (c->profile) (void)hipEventRecord(c->prof_ev[1][1], s);
+    if (c->profile) { (void)hipEventRecord(c->prof_event(1, 1), s); ++c->hist_count[1]; }
     release_tab();
     return 0;
 }
@@ -1506,7 +1519,32 @@ int daam_profile_enable(DaamCtx* c, int on)
         for (auto& pair : c->prof_ev)
             for (auto& ev : pair) HIP_TRY(hipEventCreate(&ev));
 
-    c->profile = on ? 1 : 0;
+    if (on == 2) {
+        for (int which = 0; which < 2; ++which)
+            for (int end = 0; end < 2; ++end)
+                if (c->hist_ev[which][end].empty()) {
+                    c->hist_ev[which][end].resize(DaamCtx::kProfHist, nullptr);
+                    for (auto& ev : c->hist_ev[which][end]) HIP_TRY(hipEventCreate(&ev));
+                }
+        c->hist_count[0] = c->hist_count[1] = 0;
+    }
+    c->profile = on == 2 ? 2 : on ? 1 : 0;
+    return 0;
+}
+
+int daam_profile_history(DaamCtx* c, int which, float* ms, int capacity, int* n)
+{
+    if (!c || !ms || !n || which < 0 || which > 1 || capacity < 0) return fail(DAAM_E_INVALID, "bad argument");
+    if (c->hist_ev[which][0].empty()) return fail(DAAM_E_STATE, "daam_profile_enable(ctx, 2) was never called");
+    DeviceGuard on_device(c);
+    const long long have = std::min<long long>(c->hist_count[which], DaamCtx::kProfHist);
+    const int take = (int)std::min<long long>(have, capacity);
+    *n = take;
+    for (int i = 0; i < take; ++i) {                       // oldest of the last `take` launches first
+        const size_t slot = (size_t)((c->hist_count[which] - take + i) % DaamCtx::kProfHist);
+        HIP_TRY(hipEventSynchronize(c->hist_ev[which][1][slot]));
+        HIP_TRY(hipEventElapsedTime(&ms[i], c->hist_ev[which][0][slot], c->hist_ev[which][1][slot]));
+    }
     return 0;
 }
 

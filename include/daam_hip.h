@@ -208,6 +208,10 @@ DAAM_API int daam_last_flush(DaamCtx* ctx, int* n_kernels, int* n_side_streams, 
  * last pair and returns the elapsed milliseconds (the only other call that synchronises the host). */
 DAAM_API int daam_profile_enable(DaamCtx* ctx, int on);
 DAAM_API int daam_profile_last_ms(DaamCtx* ctx, int which /*0 tap,1 finalize*/, float* ms);
+/* daam_profile_enable(ctx, 2): every launch of a kind gets its own event pair (a ring of 256), so that a whole timed region can be
+ * measured without a host synchronisation inside it; daam_profile_history then returns the durations (ms, oldest first) of the last
+ * min(launches since the enable, 256, capacity) launches of `which`. */
+DAAM_API int daam_profile_history(DaamCtx* ctx, int which /*0 tap,1 finalize*/, float* ms, int capacity, int* n);
 /* Shader-clock monitor for issue-rate rooflines: one wave on an internal stream takes `n_samples` (<= 4096) samples, `period_us`
  * apart, of the shader-cycle counter (s_memtime) and the constant 100 MHz reference counter (s_memrealtime) while the caller
  * runs the kernels under test on its own stream; _read waits for the monitor and returns the clock of every sampling

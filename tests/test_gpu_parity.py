@@ -417,6 +417,41 @@ def test_raw_abi_strides_past_32_bit_offsets_fall_back():
     del big
 
 
+def test_profile_history_times_every_launch_of_a_region():
+    """daam_profile_enable(ctx, 2) + daam_profile_history: one HIP-event pair per tap launch / finalize call out of a ring, read back
+    after the region (what bench.py's roofline.ms_per_launch is made of) -- counts, order, capacity clipping, and plausible durations."""
+    import ctypes
+    from daam_amd import _native as nat
+    rng = np.random.default_rng(3)
+    heads, side, d = 2, 32, 64
+    q, k = _qk(rng, 2, heads, side * side, d, np.float16)
+    qd, kd = _dev(q), _dev(k)
+    eng = _engine(n_layers=1, defer_steps=8)
+    eng.tap_qk(0, qd, kd, heads, d ** -0.5, 2)
+    eng.global_heat_map()                                            # creates the context, warms up
+    nat.check(eng.lib.daam_profile_enable(eng.ctx, 2))
+    steps = [1, 3, 5, 2]                                             # steps per generation: launch durations grow with them
+    for n in steps:
+        eng.clear()
+        for _ in range(n):
+            eng.tap_qk(0, qd, kd, heads, d ** -0.5, 2)
+        eng.global_heat_map()
+
+    def history(which, cap):
+        buf = (ctypes.c_float * 16)()
+        got = ctypes.c_int()
+        nat.check(eng.lib.daam_profile_history(eng.ctx, which, buf, cap, ctypes.byref(got)))
+        return [buf[i] for i in range(got.value)]
+    tap, fin = history(0, 16), history(1, 16)
+    assert len(tap) == len(steps) and len(fin) == len(steps)
+    assert all(0.0 < t < 50.0 for t in tap + fin), (tap, fin)
+    assert history(0, 2) == tap[-2:]                                 # clipped to the newest launches, oldest first
+    nat.check(eng.lib.daam_profile_enable(eng.ctx, 2))               # re-arming starts a new region
+    assert history(0, 16) == []
+    nat.check(eng.lib.daam_profile_enable(eng.ctx, 0))
+    eng.close()
+
+
 def test_views_survive_clear_and_next_generation():
     """``all_heat_maps`` hands out views of the live sums; like the reference's tensors (heatmap.py:170-172: clear() drops the
     dict, tensors handed out before live on) they must keep their values through clear() AND through the next
