@@ -56,6 +56,36 @@ def test_bench_eight_ranks_one_device():
     assert rec['value'] > 0 and rec['roofline']['launches_per_generation'] == 1
 
 
+def test_bench_comm_over_rccl_single_rank():
+    """bench.py's collective layer on the PRODUCTION backend (``nccl`` = RCCL), as far as one GPU allows: a one-rank process group --
+    communicator initialisation with ``device_id``, ``all_gather_into_tensor`` of device maps, the MAX all-reduce, the library stamp
+    of the JSON line.  (RCCL refuses two ranks on one device; more ranks run over gloo above and on the driver's 8-GPU node.)"""
+    code = (
+        "import os, sys, torch\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "torch.cuda.set_device(0)\n"
+        "comm = bench.Comm('nccl', torch.device('cuda', 0))\n"
+        "assert (comm.world, comm.rank) == (1, 0)\n"
+        "mine = torch.arange(3 * 77 * 64 * 64, device='cuda:0', dtype=torch.float32).view(3, 77, 64, 64)\n"
+        "comm.barrier()\n"
+        "got = comm.all_gather(mine)\n"
+        "assert got.shape == mine.shape and torch.equal(got, mine)\n"
+        "assert comm.max(2.5) == 2.5\n"
+        "lib = comm.library()\n"
+        "assert lib.startswith('RCCL') and 'world_size 1' in lib, lib\n"
+        "comm.close()\n"
+        "print('RCCL_OK', lib)\n")
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0 and 'RCCL_OK' in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
 def test_bench_refuses_more_gpus_than_visible():
     import torch
     n = torch.cuda.device_count() + 1
