@@ -46,7 +46,7 @@ extern "C" {
 /* element types of activations (q, k, probs) and of the running sums */
 #define DAAM_F16 0
 #define DAAM_F32 1
-#define DAAM_BF16 2         /* bfloat16 pipelines: bf16 logits / probabilities / sums (MFMA tap for head_dim <= 64) */
+#define DAAM_BF16 2         /* bfloat16 pipelines: bf16 logits / probabilities / sums (MFMA taps for every head_dim that is a multiple of 8, <= 256) */
 
 /* DAAM_E_* */
 #define DAAM_E_INVALID   (-1)   /* bad argument / shape / dtype */
