@@ -22,7 +22,8 @@ bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t 
 int tap_mfma_tile_pixels();
 int tap_mfma_ksteps(int head_dim);
 int tap_mfma_max_steps();
-hipError_t launch_tap_d64(const TapLaunch&, int in_dtype, int acc_dtype, int fast_exp, int full64, hipStream_t, int*, int*);
+hipError_t launch_tap_d64(const TapLaunch&, int in_dtype, int acc_dtype, int fast_exp, int full64, int waves8, hipStream_t, int*, int*);
+int tap_d64_tile_pixels(int in_dtype, int acc_dtype, int full64);
 bool tap_wide_supported(int in_dtype, int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                         const void* q, const void* k);
 hipError_t launch_tap_wide(const TapLaunch&, int acc_dtype, int max_head_dim, int fast_exp, hipStream_t, int*, int*);
@@ -204,6 +205,7 @@ struct DaamCtx {
     std::vector<char> fin_tab_host;   // the bytes d_fin_tab holds (when fin_tab_valid)
     bool fin_tab_valid = false;
     hipStream_t fin_tab_stream = nullptr;   // the stream its upload and its readers were enqueued on
+    int no_w8 = 0;                    // debugging / A-B: DAAM_TAP_W8=0 (head_dim-64 launches on 4-wave workgroups of 128 pixels instead of 8-wave / 256)
     int no_fin_cache = 0;             // debugging / A-B: DAAM_NO_FIN_CACHE=1 (tables through the ring + zeroing in every call)
     // daam_finalize_prepare: the output buffer the next daam_finalize accumulates into has been zeroed already (prep_*), or is to
     // be zeroed by the table-upload kernel of the next tap launch (fold_*)
@@ -416,6 +418,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->no_pipe_finalize = npp && npp[0] == '1';
     const char* npf = getenv("DAAM_NO_PAIRED_FINALIZE");
     c->no_paired_finalize = npf && npf[0] == '1';
+    const char* w8 = getenv("DAAM_TAP_W8");
+    c->no_w8 = w8 && w8[0] == '0';
     const char* nfc = getenv("DAAM_NO_FIN_CACHE");
     c->no_fin_cache = nfc && nfc[0] == '1';
     const char* n16 = getenv("DAAM_NO_D64");            // debugging: 32x32-tile kernel also for head_dim 64
@@ -725,7 +729,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
     L.wgs_per_xcd = (L.total_wgs + 7) / 8;
     c->last_block[0] = 256;
     const int kd1 = mfma ? mfma_kind(c, *d, q, k) : 0;
-    hipError_t e = (kd1 == 65 || kd1 == 66) ? launch_tap_d64(L, d->in_dtype, c->acc_dtype, c->fast_exp && d->round_logits, d->head_dim == 64, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
+    hipError_t e = (kd1 == 65 || kd1 == 66) ? launch_tap_d64(L, d->in_dtype, c->acc_dtype, c->fast_exp && d->round_logits, d->head_dim == 64, 0, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : (kd1 == 67 || kd1 == 69) ? launch_tap_wide(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : kd1 == 70 ? launch_tap_chunk(L, d->in_dtype, c->acc_dtype, c->fast_exp && d->round_logits, 0, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
                    : mfma ? launch_tap_mfma(L, c->acc_dtype, d->head_dim, c->fast_exp && d->round_logits, (hipStream_t)stream, &c->last_grid[0], &c->last_lds[0])
@@ -915,13 +919,23 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     int rc = 0;
     int grid_total = 0;
     // pass 1: the tables of every kernel kind -> ring -> device (all on the caller's stream)
-    struct Prepared { int kd; TapLaunch L; int max_d; int min_d; int all_round; size_t ring_begin, ring_end; };
+    struct Prepared { int kd; TapLaunch L; int max_d; int min_d; int all_round; size_t ring_begin, ring_end; bool w8; };
     std::vector<Prepared> prepared;
     for (int kd : kinds) {
         size_t n_layers = 0, n_ptrs = 0;
         for (size_t i = 0; i < order.size(); ++i)
             if (kind[i] == kd) { ++n_layers; n_ptrs += per[i].size(); }
-        const int tile = kd ? tap_mfma_tile_pixels() : kTapPixels;
+        int tile = kd ? tap_mfma_tile_pixels() : kTapPixels;
+        bool w8 = false;
+        if (kd == 65 && !c->no_w8) {
+            // head_dim-64 launches with fp16 Q / K and fp16 sums: 256-pixel tiles on eight-wave workgroups (one K tile for twice the pixels)
+            bool full64 = true;
+            for (size_t i = 0; i < order.size(); ++i)
+                if (kind[i] == kd) full64 = full64 && per[i][0]->d.head_dim == 64;
+            const int t8 = tap_d64_tile_pixels(in_dtype, c->acc_dtype, full64 ? 1 : 0);
+            w8 = t8 != tile;
+            tile = t8;
+        }
         if (!kd) {                                           // the generic kernel reads the sums first
             for (size_t i = 0; i < order.size() && !rc; ++i)
                 if (kind[i] == kd) rc = ensure_zeroed(c->layers[order[i]], s);
@@ -970,6 +984,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         pr.max_d = max_d;
         pr.min_d = min_d;
         pr.all_round = all_round;
+        pr.w8 = w8;
         pr.ring_begin = c->ring.cur_begin;
         pr.ring_end = c->ring.cur_end;
         prepared.push_back(pr);
@@ -1028,7 +1043,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             if (ge != hipSuccess) { rc = fail((int)ge, "start gate: %s", hipGetErrorString(ge)); break; }
         }
         int grid = 0;
-        hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, ks, &grid, &c->last_lds[0])
+        hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, pr.w8 ? 1 : 0, ks, &grid, &c->last_lds[0])
                      : (pr.kd == 67 || pr.kd == 69) ? launch_tap_wide(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
                      : pr.kd == 70 ? launch_tap_chunk(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d != pr.max_d, ks, &grid, &c->last_lds[0])
                      : pr.kd ? launch_tap_mfma(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
@@ -1053,6 +1068,8 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     if (c->profile && ev_started) { (void)hipEventRecord(c->prof_event(0, 1), s); ++c->hist_count[0]; }
     c->last_grid[0] = grid_total;
     c->last_block[0] = 256;
+    for (auto& pr : prepared)
+        if (pr.w8) c->last_block[0] = 512;
     c->last_flush_kernels = (int)launch_order.size();
     c->last_flush_side = n_side;
     c->last_flush_steps = 0;

@@ -49,6 +49,14 @@
 #ifndef DAAM_TAP_EARLY_DMA
 #define DAAM_TAP_EARLY_DMA 1
 #endif
+// EIGHT waves per workgroup for the head_dim-64 launches with fp16 sums (the headline): 256 pixels of one head share ONE K tile.  Every
+// workgroup-step pulls its head's K tile (10 KB) out of L2 next to its Q rows (4 KB per wave); with 128-pixel workgroups that is 38 % of
+// what the CUs take in, and fetching it only every other step (-DDAAM_TAP_ABLATE=7, wrong results) made the launch 4 % shorter / +4.6 %
+// heat maps / s (LABNOTES R4.7).  Two workgroups of eight waves per CU = the same 4 waves per SIMD, 53 KB of LDS each.
+// -DDAAM_TAP_W8=0 (or DAAM_TAP_W8=0 in the environment) for A/B runs.
+#ifndef DAAM_TAP_W8
+#define DAAM_TAP_W8 1
+#endif
 
 // TLB-warming touch (experiment, off by default; -DDAAM_TAP_TOUCH=N): a wave reads ONE dword of the Q rows and of the K tensor it
 // will fetch N steps later.  Why: the launch time depends on the FOOTPRINT of the recorded Q / K, not only on the bytes moved
@@ -65,8 +73,9 @@ constexpr int kTapKBuf = kD64Rows * kTapRow;        // 10240: 80 K rows, rows 77
 constexpr int kTapQTile = 32 * kTapRow;             // 4096: one wave's 32 pixel rows
 constexpr int kTapQOff = 2 * kTapKBuf;              // Q tiles of the four waves follow the two K buffers
 
-template <typename ACC_T> constexpr size_t tap_d64_lds_bytes() {
-    const size_t kb = 2 * (size_t)kTapKBuf + 4 * (size_t)kTapQTile, st = (size_t)kTok * kMfmaPixels * sizeof(ACC_T);
+// WAVES = waves per workgroup: 4 (128 pixels) or 8 (256 pixels of one head, ONE K tile for twice the pixels: see DAAM_TAP_W8)
+template <typename ACC_T, int WAVES = 4> constexpr size_t tap_d64_lds_bytes() {
+    const size_t kb = 2 * (size_t)kTapKBuf + WAVES * (size_t)kTapQTile, st = (size_t)kTok * (32 * WAVES) * sizeof(ACC_T);
     return (kb > st ? kb : st) + (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*) + (DAAM_TAP_TOUCH ? 256 : 0);     // fp16 sums: 37888 -> 4 workgroups per CU
 }
 
@@ -75,18 +84,21 @@ __device__ __forceinline__ constexpr int swz_chunk(int row, int chunk) { return 
 
 // FULL64: every layer of the launch has head_dim == 64 (SDXL): the zero-padding selects of the head_dim < 64 case (8 VALU per
 // wave-step) are compiled out
-template <typename IN, typename ACC_T, bool FAST_EXP, bool FULL64>
-__global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
+template <typename IN, typename ACC_T, bool FAST_EXP, bool FULL64, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
 {
+    constexpr int NT = 64 * WAVES;                            // threads per workgroup
+    constexpr int TILE = 32 * WAVES;                          // pixels per workgroup (the host sizes tiles_per_head with it)
+    static_assert(WAVES == 4 || (WAVES == 8 && FULL64 && DAAM_TAP_DMA), "eight waves: head_dim-64 launches on the DMA path only");
     constexpr int KCH = (kTok * 8 + 255) / 256;               // 16-B K pieces per thread per step (3)
     constexpr int VEC = AccVec<ACC_T>::kPerVec;
-    constexpr int PPR = kMfmaPixels / VEC;
-    constexpr size_t kPtrOff = tap_d64_lds_bytes<ACC_T>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*) - (DAAM_TAP_TOUCH ? 256 : 0);
-    [[maybe_unused]] constexpr size_t kTouchOff = tap_d64_lds_bytes<ACC_T>() - 256;     // DAAM_TAP_TOUCH: 256 bytes nobody reads
+    constexpr int PPR = TILE / VEC;
+    constexpr size_t kPtrOff = tap_d64_lds_bytes<ACC_T, WAVES>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*) - (DAAM_TAP_TOUCH ? 256 : 0);
+    [[maybe_unused]] constexpr size_t kTouchOff = tap_d64_lds_bytes<ACC_T, WAVES>() - 256;     // DAAM_TAP_TOUCH: 256 bytes nobody reads
 
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* kbuf = smem;                               // [2][kTapKBuf], then the four waves' Q tiles
-    ACC_T* stage = reinterpret_cast<ACC_T*>(smem);            // [kTok][kMfmaPixels], aliases both
+    ACC_T* stage = reinterpret_cast<ACC_T*>(smem);            // [kTok][TILE], aliases both
     const void** sptr = reinterpret_cast<const void**>(smem + kPtrOff);
 
     const int wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     const int tid = threadIdx.x;
     if (table) {
         const DAAM_GLOBAL TapPtr* ptrs = as_global<TapPtr>(L.ptrs) + lay.ptr_begin;
-        for (int i = tid; i < lay.n_steps; i += 256) {
+        for (int i = tid; i < lay.n_steps; i += NT) {
             sptr[2 * i] = ptrs[i].q;
             sptr[2 * i + 1] = ptrs[i].k;
         }
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     const int n_steps = lay.n_steps;
     const int rel = wg - lay.wg_begin;
     const int kh = rel / lay.tiles_per_head;
-    const int p0 = (rel - kh * lay.tiles_per_head) * kMfmaPixels;
+    const int p0 = (rel - kh * lay.tiles_per_head) * TILE;
     const int bh = lay.bh_first + kh;
     const int b = bh / lay.heads, hd = bh - b * lay.heads;
     const int64_t k_off = b * lay.k_sb + hd * lay.k_sh;
@@ -131,10 +143,10 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     typename Pair<ACC_T>::T run0[kSlots16 / 2], run1[kSlots16 / 2];   // slot pairs (2i, 2i+1)
     ACC_T* acc = reinterpret_cast<ACC_T*>(lay.acc) + (size_t)kh * kTok * lay.hw;
     if (!lay.fresh) {
-        for (int piece = tid; piece < kTok * PPR; piece += 256) {
+        for (int piece = tid; piece < kTok * PPR; piece += NT) {
             const int row = piece / PPR, col = (piece - row * PPR) * VEC;
             if (p0 + col < lay.hw)
-                *reinterpret_cast<float4v*>(stage + row * kMfmaPixels + col) =
+                *reinterpret_cast<float4v*>(stage + row * TILE + col) =
                     *as_global<float4v>(acc + (size_t)row * lay.hw + p0 + col);
         }
         __syncthreads();
@@ -142,8 +154,8 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         for (int i = 0; i < kSlots16; ++i) {
             const int t = slot16_token(i, h);
             if (t < kTok) {
-                run0[i >> 1][i & 1] = from_acc<ACC_T>(stage[t * kMfmaPixels + wave * 32 + j]);
-                run1[i >> 1][i & 1] = from_acc<ACC_T>(stage[t * kMfmaPixels + wave * 32 + 16 + j]);
+                run0[i >> 1][i & 1] = from_acc<ACC_T>(stage[t * TILE + wave * 32 + j]);
+                run1[i >> 1][i & 1] = from_acc<ACC_T>(stage[t * TILE + wave * 32 + 16 + j]);
             } else {
                 run0[i >> 1][i & 1] = 0;
                 run1[i >> 1][i & 1] = 0;
@@ -160,12 +172,12 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     const int d = lay.head_dim;
     const bool partial = !FULL64 && d < 64;                   // wave-uniform
     if (partial) {
-        for (int i = tid; i < 2 * kTapKBuf / 16; i += 256)
+        for (int i = tid; i < 2 * kTapKBuf / 16; i += NT)
             *reinterpret_cast<float4v*>(kbuf + i * 16) = float4v{0, 0, 0, 0};
         __syncthreads();                                      // the first K tile lands on top of the zeros
     } else {
         // K rows 77..79 (never written by a step) must be finite: zero them once, both buffers
-        for (int i = tid; i < 2 * 3 * (kTapRow / 16); i += 256) {
+        for (int i = tid; i < 2 * 3 * (kTapRow / 16); i += NT) {
             const int buf = i / (3 * (kTapRow / 16)), r = i % (3 * (kTapRow / 16));
             *reinterpret_cast<float4v*>(kbuf + buf * kTapKBuf + kTok * kTapRow + r * 16) = float4v{0, 0, 0, 0};
         }
@@ -245,14 +257,14 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     };
 
 #if DAAM_TAP_DMA
-    // LDS-DMA form (FULL64 launches only).  K: 1 KiB block blk = 4 j2 + wave (10 blocks: rows 8 blk .. 8 blk + 7; rows 77..79 re-read
+    // LDS-DMA form (FULL64 launches only).  K: 1 KiB block blk = WAVES j2 + wave (10 blocks: rows 8 blk .. 8 blk + 7; rows 77..79 re-read
     // row 76: finite, their logits are masked); lane -> row 8 blk + (lane >> 3), LDS chunk slot lane & 7 = source chunk
     // (lane & 7) ^ ((row >> 1) & 7).  Q: block i = rows 8 i .. 8 i + 7 of the wave's 32, same rule.
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     unsigned kd_src[3];
 #pragma unroll
     for (int j2 = 0; j2 < 3; ++j2) {
-        const int blk = 4 * j2 + wave;
+        const int blk = WAVES * j2 + wave;
         const int row = min(8 * blk + (lane >> 3), kTok - 1);
         const int ch = (lane & 7) ^ (((8 * blk + (lane >> 3)) >> 1) & 7);
         kd_src[j2] = (unsigned)((row * (int)lay.k_st + ch * 8) * 2);
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
         const __amdgpu_buffer_rsrc_t kt = tensor(sptr[2 * s + 1]);
 #pragma unroll
         for (int j2 = 0; j2 < 3; ++j2) {
-            const int blk = 4 * j2 + wave;                    // wave-uniform
+            const int blk = WAVES * j2 + wave;                // wave-uniform
             if (blk < 10)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(kt, (lds_ptr_t)(kbuf + buf * kTapKBuf + blk * 1024), 16, kd_src[j2], k_base, 0, 0);
         }
@@ -425,16 +437,16 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     for (int i = 0; i < kSlots16; ++i) {
         const int t = slot16_token(i, h);
         if (t < kTok) {
-            stage[t * kMfmaPixels + wave * 32 + j] = to_acc<ACC_T>(run0[i >> 1][i & 1]);
-            stage[t * kMfmaPixels + wave * 32 + 16 + j] = to_acc<ACC_T>(run1[i >> 1][i & 1]);
+            stage[t * TILE + wave * 32 + j] = to_acc<ACC_T>(run0[i >> 1][i & 1]);
+            stage[t * TILE + wave * 32 + 16 + j] = to_acc<ACC_T>(run1[i >> 1][i & 1]);
         }
     }
     __syncthreads();
-    for (int piece = tid; piece < kTok * PPR; piece += 256) {
+    for (int piece = tid; piece < kTok * PPR; piece += NT) {
         const int row = piece / PPR, col = (piece - row * PPR) * VEC;
         if (p0 + col < lay.hw)
             *as_global_rw<float4v>(acc + (size_t)row * lay.hw + p0 + col) =
-                *reinterpret_cast<const float4v*>(stage + row * kMfmaPixels + col);
+                *reinterpret_cast<const float4v*>(stage + row * TILE + col);
     }
 }
 
@@ -449,42 +461,59 @@ bool tap_d64_supported(int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t
     return ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
 }
 
-template <typename IN, typename ACC_T, bool FAST, bool FULL64>
+template <typename IN, typename ACC_T, bool FAST, bool FULL64, int WAVES = 4>
 static hipError_t launch_d64_k(const TapLaunch& L, hipStream_t stream, int grid, size_t lds)
 {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_d64_kernel<IN, ACC_T, FAST, FULL64>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_d64_kernel<IN, ACC_T, FAST, FULL64, WAVES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((tap_d64_kernel<IN, ACC_T, FAST, FULL64>), dim3(grid), dim3(256), lds, stream, L);
+    hipLaunchKernelGGL((tap_d64_kernel<IN, ACC_T, FAST, FULL64, WAVES>), dim3(grid), dim3(64 * WAVES), lds, stream, L);
     return hipGetLastError();
 }
 
 template <typename IN, typename ACC_T, bool FAST>
-static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out, bool full64)
+static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out, bool full64, bool waves8)
 {
+    constexpr bool kW8Build = (DAAM_TAP_W8 != 0) & (DAAM_TAP_DMA != 0);
+    if constexpr (kW8Build && sizeof(ACC_T) == 2 && !IN::kBf16) {
+        if (waves8 && full64) {
+            const size_t lds8 = tap_d64_lds_bytes<ACC_T, 8>();
+            *lds_out = lds8;
+            return launch_d64_k<IN, ACC_T, FAST, true, 8>(L, stream, grid, lds8);
+        }
+    }
+    if (waves8) return hipErrorInvalidValue;                  // the host sized the tiles for eight waves: no other form may run them
     const size_t lds = tap_d64_lds_bytes<ACC_T>();
     *lds_out = lds;
     return full64 ? launch_d64_k<IN, ACC_T, FAST, true>(L, stream, grid, lds) : launch_d64_k<IN, ACC_T, FAST, false>(L, stream, grid, lds);
 }
 
-hipError_t launch_tap_d64(const TapLaunch& L, int in_dtype, int acc_dtype, int fast_exp, int full64, hipStream_t stream, int* grid_out, int* lds_out)
+// tile pixels the host must size a head_dim-64 launch for: 256 when the eight-wave form takes it (fp16 Q / K, fp16 sums, every layer
+// head_dim 64), else 128
+int tap_d64_tile_pixels(int in_dtype, int acc_dtype, int full64)
+{
+    constexpr bool kW8Build = (DAAM_TAP_W8 != 0) & (DAAM_TAP_DMA != 0);
+    return (kW8Build && in_dtype == 0 && acc_dtype == 0 && full64) ? 256 : 128;
+}
+
+hipError_t launch_tap_d64(const TapLaunch& L, int in_dtype, int acc_dtype, int fast_exp, int full64, int waves8, hipStream_t stream, int* grid_out, int* lds_out)
 {
     const int grid = L.wgs_per_xcd * 8;
     *grid_out = grid;
     size_t lds = 0;
     hipError_t e;
     if (in_dtype == 2) {                                       // bf16 pipeline: one softmax flavour
-        if (acc_dtype == 2) e = launch_d64<InBF16, bf16_t, true>(L, stream, grid, &lds, full64 != 0);
-        else if (acc_dtype == 1) e = launch_d64<InBF16, float, true>(L, stream, grid, &lds, full64 != 0);
+        if (acc_dtype == 2) e = launch_d64<InBF16, bf16_t, true>(L, stream, grid, &lds, full64 != 0, waves8 != 0);
+        else if (acc_dtype == 1) e = launch_d64<InBF16, float, true>(L, stream, grid, &lds, full64 != 0, waves8 != 0);
         else return hipErrorInvalidValue;
     } else if (acc_dtype != 0 && acc_dtype != 1) {
         return hipErrorInvalidValue;
     } else if (fast_exp) {
-        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, true>(L, stream, grid, &lds, full64 != 0) : launch_d64<InF16, float, true>(L, stream, grid, &lds, full64 != 0);
+        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, true>(L, stream, grid, &lds, full64 != 0, waves8 != 0) : launch_d64<InF16, float, true>(L, stream, grid, &lds, full64 != 0, waves8 != 0);
     } else {
-        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, false>(L, stream, grid, &lds, full64 != 0) : launch_d64<InF16, float, false>(L, stream, grid, &lds, full64 != 0);
+        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, false>(L, stream, grid, &lds, full64 != 0, waves8 != 0) : launch_d64<InF16, float, false>(L, stream, grid, &lds, full64 != 0, waves8 != 0);
     }
     *lds_out = (int)lds;
     return e;
