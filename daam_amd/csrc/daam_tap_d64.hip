@@ -11,7 +11,8 @@
 // Same arithmetic / rounding points as daam_tap_mfma.hip:
 //   logits = fp16(f32(q.k) * scale) -> f32 softmax -> fp16(p) -> acc += p (accumulator dtype).
 //
-// Workgroup = 256 threads = 4 waves = 128 pixels of one (layer, kept head); wave w: pixels
+// Workgroup = 4 waves = 128 pixels of one (layer, kept head) -- or, for head_dim-64 launches with fp16 sums since round 4, 8 waves = 256
+// pixels sharing ONE K tile (template parameter WAVES, DAAM_TAP_W8 below); wave w: pixels
 // [32w, 32w+32) = groups 0 / 1 of 16.  "Swapped" product S^T = K Q^T: A = K rows (lane: token row
 // l&15 of the 16-row tile, k = 8*(l>>4)..+7 of the 32-wide k-step), B = Q^T (lane: pixel l&15, same
 // k split).  C/D: lane holds pixel l&15 and tokens 16*mt + 4*(l>>4) + r (mt = 0..4, r = 0..3) = 20 slots.
