@@ -317,7 +317,11 @@ __global__ __launch_bounds__(64 * WAVES, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4
 #endif
 #if DAAM_TAP_DMA && DAAM_TAP_EARLY_DMA
         // the K buffer of step s + 1 was last read in step s - 1 and every wave is past this step's barrier: its DMAs go out first
+#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 7            // timing experiment 7: the K tile only every other pair of steps (half the K traffic;
+        if constexpr (FULL64) { if (s & 2) dma_k(s_fetch, (s + 1) & 1); }   // results are wrong): the ceiling of sharing one K tile between more pixels
+#else
         if constexpr (FULL64) dma_k(s_fetch, (s + 1) & 1);
+#endif
 #endif
         const half8 q00 = *reinterpret_cast<const half8*>(qtile + f_rd), q01 = *reinterpret_cast<const half8*>(qtile + (f_rd ^ 64));
         const half8 q10 = *reinterpret_cast<const half8*>(qtile + 16 * kTapRow + f_rd);
