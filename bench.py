@@ -417,7 +417,7 @@ def load_counters():
     return None, note
 
 
-_TAP_KERNELS = ('tap_d64_kernel', 'tap_chunk_kernel', 'tap_wide_kernel', 'tap_mfma_kernel', 'tap_generic_kernel')
+_TAP_KERNELS = ('tap_d64_kernel', 'tap_slab_kernel', 'tap_chunk_kernel', 'tap_wide_kernel', 'tap_mfma_kernel', 'tap_generic_kernel')
 _FIN_KERNELS = ('finalize_up32_pipe_kernel', 'finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_down2_kernel',
                 'finalize_up_kernel', 'finalize_same_kernel', 'finalize_kernel')
 
@@ -696,6 +696,8 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
         rec = {k: v for k, v in rec.items() if not k.startswith('tap_')}
     traffic = rec.get('tap_bytes_per_launch') if rec else None
     tap_kernel = ('tap_d64_kernel (16x16x32 MFMA tiles, head_dim 64)' if wl['kind'] == 'sdxl'
+                  else 'tap_slab_kernel (head_dim 40 / 80 / 160: 640-byte slabs of adjacent heads, whole 128-byte lines of Q, every layer in ONE launch)'
+                  if flush['kernels'] == 1 and os.environ.get('DAAM_TAP_SLAB', '1') != '0' and args.accumulate in ('exact', 'float32')
                   else 'tap_chunk_kernel (head_dim 40 / 80 / 160 in 64-element chunks, every layer in ONE launch)' if flush['kernels'] == 1
                   else 'tap_d64_kernel (head_dim 40) + tap_wide_kernel<3|5> (head_dim 80 / 160), one flush = 3 kernels side by side')
     out['roofline'] = dict(bound='hbm', kernel=tap_kernel,

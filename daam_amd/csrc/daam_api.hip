@@ -32,6 +32,11 @@ bool tap_d64_supported(int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t
 bool tap_chunk_supported(int in_dtype, int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_sh,
                          int64_t q_extent, const void* q, const void* k);
 hipError_t launch_tap_chunk(const TapLaunch&, int in_dtype, int acc_dtype, int fast_exp, int interleave, hipStream_t, int*, int*);
+bool tap_slab_supported(int in_dtype, int batch, int heads, int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t q_sb, int64_t q_sh, int64_t k_sb,
+                        int64_t k_sh, int64_t q_extent, const void* q, const void* k);
+int tap_slab_heads(int head_dim);
+int tap_slab_tile_pixels();
+hipError_t launch_tap_slab(const TapLaunch&, int acc_dtype, int fast_exp, hipStream_t, int*, int*);
 
 hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int*);
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
@@ -252,6 +257,8 @@ struct DaamCtx {
     int force_generic = 0;
     int fast_exp = 0;
     int no_d64 = 0;
+    int tap_slab = 1;                 // tap_slab_kernel (daam_tap_slab.hip): deferred fp16 layers of head_dim 40 / 80 / 160 in 640-byte slabs of adjacent heads
+                                      // (whole 128-byte lines of Q: SD-v1.x); DAAM_TAP_SLAB=0 leaves them to the kernels below
     int tap_chunked = 2;              // tap_chunk_kernel (fp16 layers of any head_dim, one kind of workgroup): 2 = for deferred launches that
                                       // mix head dims (default), 1 = for every fp16 layer (DAAM_TAP_CHUNKED=1), 0 = never (DAAM_TAP_CHUNKED=0)
 };
@@ -426,6 +433,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->no_d64 = n16 && n16[0] == '1';
     const char* nss = getenv("DAAM_NO_SIDE_STREAM");        // debugging / A-B: every tap kernel of a flush on the caller's stream
     c->no_side_stream = nss && nss[0] == '1';
+    const char* tsl = getenv("DAAM_TAP_SLAB");
+    c->tap_slab = !(tsl && tsl[0] == '0');
     const char* tck = getenv("DAAM_TAP_CHUNKED");           // daam_tap_chunk.hip: unset = launches that mix head dims, 1 = always, 0 = never
     c->tap_chunked = !tck || !tck[0] ? 2 : tck[0] == '1' ? 1 : tck[0] == '0' ? 0 : 2;
 
@@ -693,6 +702,16 @@ static bool chunk_ok(const DaamCtx* c, const DaamQKDesc& d, const void* q, const
                                d.k_stride_h, (int64_t)d.batch * d.q_stride_b, q, k);
 }
 
+// the slab kernel (daam_tap_slab.hip) can take this deferred call: fp16 Q / K, fp16 or f32 sums, head_dim 40 / 80 / 160 with the heads
+// adjacent in the rows
+static bool slab_ok(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
+{
+    if (!c->tap_slab || c->no_d64 || c->force_generic || d.tokens != 77 || d.in_dtype != DAAM_F16 || !offsets_fit_32(d)) return false;
+    if (!(c->acc_dtype == DAAM_F16 || c->acc_dtype == DAAM_F32)) return false;
+    return tap_slab_supported(d.in_dtype, d.batch, d.heads, d.head_dim, d.hw, d.q_stride_p, d.k_stride_t, d.q_stride_b, d.q_stride_h, d.k_stride_b,
+                              d.k_stride_h, (int64_t)d.batch * d.q_stride_b, q, k);
+}
+
 // DAAM_TAP_CHUNKED=1: every such call.  Default (2): the deferred launches that mix head dims (daam_tap_flush), and bf16 layers with
 // head_dim > 64 -- no other MFMA kernel has a bf16 form for them (the any-shape kernel is ~45x slower per step).
 static bool use_chunk(const DaamCtx* c, const DaamQKDesc& d, const void* q, const void* k)
@@ -913,6 +932,16 @@ int daam_tap_flush(DaamCtx* c, void* stream)
                     if (kd == 65 || kd == 66 || kd == 67 || kd == 69) kd = 70;
         }
     }
+    // fp16 layers of head_dim 40 / 80 / 160 (SD-v1.x) whose every recorded step qualifies: the slab kernel -- whole 128-byte lines of Q,
+    // ONE launch for the three head dims (bit-identical sums: tests/test_gpu_slab.py).  DAAM_TAP_CHUNKED=0 / 1 pin the older kernels.
+    if (c->tap_slab && c->tap_chunked == 2 && in_dtype == DAAM_F16) {
+        for (size_t i = 0; i < kind.size(); ++i) {
+            if (!(kind[i] == 65 || kind[i] == 67 || kind[i] == 69 || kind[i] == 70) || !tap_slab_heads(per[i][0]->d.head_dim)) continue;
+            bool ok = true;
+            for (const Pending* p : per[i]) ok = ok && slab_ok(c, p->d, p->q, p->k);
+            if (ok) kind[i] = 71;
+        }
+    }
     std::vector<int> kinds;
     for (int kd : kind)
         if (std::find(kinds.begin(), kinds.end(), kd) == kinds.end()) kinds.push_back(kd);
@@ -925,9 +954,9 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         size_t n_layers = 0, n_ptrs = 0;
         for (size_t i = 0; i < order.size(); ++i)
             if (kind[i] == kd) { ++n_layers; n_ptrs += per[i].size(); }
-        int tile = kd ? tap_mfma_tile_pixels() : kTapPixels;
+        int tile = kd == 71 ? tap_slab_tile_pixels() : kd ? tap_mfma_tile_pixels() : kTapPixels;
         bool w8 = false;
-        if (kd == 65 && !c->no_w8) {
+        if ((kd == 65 || kd == 66) && !c->no_w8) {
             // head_dim-64 launches with fp16 Q / K and fp16 sums: 256-pixel tiles on eight-wave workgroups (one K tile for twice the pixels)
             bool full64 = true;
             for (size_t i = 0; i < order.size(); ++i)
@@ -949,20 +978,36 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         TapPtr* hp = reinterpret_cast<TapPtr*>(c->ring.host + off + bytes_layers);
         int wg = 0, ptr = 0, max_d = 0, min_d = 1 << 30, all_round = 1;
         size_t j = 0;
-        for (size_t i = 0; i < order.size(); ++i) {
-            if (kind[i] != kd) continue;
+        std::vector<size_t> sel;
+        for (size_t i = 0; i < order.size(); ++i)
+            if (kind[i] == kd) sel.push_back(i);
+        // slab kernel: the layers segment by segment (one head_dim = one cost per workgroup each): head_dim 160 first (few, light workgroups
+        // with the longest step chains), 40 (the bulk), 80 last (the short chains fill the tail); every XCD takes an eighth of each segment
+        int seg_begin[5] = {0, 0, 0, 0, 0}, n_seg = 0;
+        auto seg_rank = [](int d) { return d == 160 ? 0 : d == 40 ? 1 : 2; };
+        if (kd == 71)
+            std::stable_sort(sel.begin(), sel.end(), [&](size_t a, size_t b) { return seg_rank(per[a][0]->d.head_dim) < seg_rank(per[b][0]->d.head_dim); });
+        int last_rank = -1;
+        for (size_t i : sel) {
             const auto& v = per[i];
             fill_layer(c, c->layers[order[i]], v[0]->d, tile, &hl[j]);
             hl[j].wg_begin = wg;
             hl[j].n_steps = (int)v.size();
             hl[j].ptr_begin = ptr;
             for (auto* p : v) { hp[ptr].q = p->q; hp[ptr].k = p->k; ++ptr; }
-            wg += hl[j].heads_kept * hl[j].tiles_per_head;
+            if (kd == 71) {
+                const int r = seg_rank(v[0]->d.head_dim);
+                if (r != last_rank) { seg_begin[n_seg++] = wg; last_rank = r; }
+                wg += hl[j].heads_kept / tap_slab_heads(v[0]->d.head_dim) * hl[j].tiles_per_head;   // tiles_per_head = tiles per slab
+            } else {
+                wg += hl[j].heads_kept * hl[j].tiles_per_head;
+            }
             max_d = std::max(max_d, v[0]->d.head_dim);
             min_d = std::min(min_d, v[0]->d.head_dim);
             all_round = all_round && v[0]->d.round_logits;
             ++j;
         }
+        seg_begin[n_seg] = wg;
         // daam_finalize_prepare: the output of the finalize that follows this launch is cleared by this (first) upload kernel
         const bool fold = c->fold_out && c->fold_stream == s;
         e = c->ring.commit(off, bytes, s, fold ? c->fold_out : nullptr, fold ? c->fold_bytes : 0);
@@ -981,6 +1026,8 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         pr.L.tokens = c->tokens;
         pr.L.total_wgs = wg;
         pr.L.wgs_per_xcd = (wg + 7) / 8;
+        pr.L.n_seg = n_seg;
+        for (int k = 0; k < 5; ++k) pr.L.seg_begin[k] = seg_begin[k];
         pr.max_d = max_d;
         pr.min_d = min_d;
         pr.all_round = all_round;
@@ -1046,6 +1093,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, pr.w8 ? 1 : 0, ks, &grid, &c->last_lds[0])
                      : (pr.kd == 67 || pr.kd == 69) ? launch_tap_wide(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
                      : pr.kd == 70 ? launch_tap_chunk(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d != pr.max_d, ks, &grid, &c->last_lds[0])
+                     : pr.kd == 71 ? launch_tap_slab(pr.L, c->acc_dtype, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
                      : pr.kd ? launch_tap_mfma(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
                              : launch_tap_generic(pr.L, in_dtype, c->acc_dtype, pr.max_d, ks, &grid, &c->last_lds[0]);
         grid_total += grid;
@@ -1069,7 +1117,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     c->last_grid[0] = grid_total;
     c->last_block[0] = 256;
     for (auto& pr : prepared)
-        if (pr.w8) c->last_block[0] = 512;
+        if (pr.w8 || pr.kd == 71) c->last_block[0] = 512;
     c->last_flush_kernels = (int)launch_order.size();
     c->last_flush_side = n_side;
     c->last_flush_steps = 0;

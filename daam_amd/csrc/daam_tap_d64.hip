@@ -50,7 +50,8 @@
 #ifndef DAAM_TAP_EARLY_DMA
 #define DAAM_TAP_EARLY_DMA 1
 #endif
-// EIGHT waves per workgroup for the head_dim-64 launches with fp16 sums (the headline): 256 pixels of one head share ONE K tile.  Every
+// EIGHT waves per workgroup for the head_dim-64 launches (round 4: fp16 Q / K with fp16 sums, the headline; round 5: also bf16 Q / K and
+// f32 sums): 256 pixels of one head share ONE K tile.  Every
 // workgroup-step pulls its head's K tile (10 KB) out of L2 next to its Q rows (4 KB per wave); with 128-pixel workgroups that is 38 % of
 // what the CUs take in, and fetching it only every other step (-DDAAM_TAP_ABLATE=7, wrong results) made the launch 4 % shorter / +4.6 %
 // heat maps / s (LABNOTES R4.7).  Two workgroups of eight waves per CU = the same 4 waves per SIMD, 53 KB of LDS each.
@@ -86,7 +87,7 @@ __device__ __forceinline__ constexpr int swz_chunk(int row, int chunk) { return 
 // FULL64: every layer of the launch has head_dim == 64 (SDXL): the zero-padding selects of the head_dim < 64 case (8 VALU per
 // wave-step) are compiled out
 template <typename IN, typename ACC_T, bool FAST_EXP, bool FULL64, int WAVES = 4>
-__global__ __launch_bounds__(64 * WAVES, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
+__global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && !IN::kBf16)) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
 {
     constexpr int NT = 64 * WAVES;                            // threads per workgroup
     constexpr int TILE = 32 * WAVES;                          // pixels per workgroup (the host sizes tiles_per_head with it)
@@ -482,7 +483,7 @@ template <typename IN, typename ACC_T, bool FAST>
 static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out, bool full64, bool waves8)
 {
     constexpr bool kW8Build = (DAAM_TAP_W8 != 0) & (DAAM_TAP_DMA != 0);
-    if constexpr (kW8Build && sizeof(ACC_T) == 2 && !IN::kBf16) {
+    if constexpr (kW8Build) {                                 // round 5: every dtype pair (bf16 Q / K and f32 sums fit 128 VGPRs at 119-128, no spills)
         if (waves8 && full64) {
             const size_t lds8 = tap_d64_lds_bytes<ACC_T, 8>();
             *lds_out = lds8;
@@ -495,12 +496,13 @@ static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, s
     return full64 ? launch_d64_k<IN, ACC_T, FAST, true>(L, stream, grid, lds) : launch_d64_k<IN, ACC_T, FAST, false>(L, stream, grid, lds);
 }
 
-// tile pixels the host must size a head_dim-64 launch for: 256 when the eight-wave form takes it (fp16 Q / K, fp16 sums, every layer
-// head_dim 64), else 128
+// tile pixels the host must size a head_dim-64 launch for: 256 when the eight-wave form takes it (every layer head_dim 64; fp16 Q / K
+// with fp16 or f32 sums, bf16 Q / K with bf16 or f32 sums), else 128
 int tap_d64_tile_pixels(int in_dtype, int acc_dtype, int full64)
 {
     constexpr bool kW8Build = (DAAM_TAP_W8 != 0) & (DAAM_TAP_DMA != 0);
-    return (kW8Build && in_dtype == 0 && acc_dtype == 0 && full64) ? 256 : 128;
+    const bool pair = (in_dtype == 0 && (acc_dtype == 0 || acc_dtype == 1)) || (in_dtype == 2 && (acc_dtype == 2 || acc_dtype == 1));
+    return (kW8Build && pair && full64) ? 256 : 128;
 }
 
 hipError_t launch_tap_d64(const TapLaunch& L, int in_dtype, int acc_dtype, int fast_exp, int full64, int waves8, hipStream_t stream, int* grid_out, int* lds_out)

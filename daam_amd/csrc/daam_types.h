@@ -61,6 +61,10 @@ struct TapLaunch {
                             // flush (daam_tap_flush) holds the large kernel back until the small ones' workgroups are resident
     TapLayer one;
     TapPtr one_ptr;
+    // tap_slab_kernel (daam_tap_slab.hip): the launch's workgroups are listed segment by segment -- [seg_begin[k], seg_begin[k + 1]) = the
+    // layers of one head_dim -- and every XCD takes an eighth of each segment
+    int32_t n_seg;
+    int32_t seg_begin[5];
 };
 
 struct ProbsLaunch {        // daam_tap_probs

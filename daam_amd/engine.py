@@ -496,9 +496,7 @@ class HeatMapEngine:
             try:
                 stream, rec_stream = self._launch_stream()
                 nat.check(self.lib.daam_tap_qk_enqueue_many(self.ctx, n, la, qa, ka, da))
-                if _before_launch is not None:
-                    _before_launch(stream)
-                nat.check(self.lib.daam_tap_flush(self.ctx, stream))
+                self._announce_then_launch(_before_launch, stream)
                 if rec_stream is not None:
                     # the Q / K blocks return to the recording stream's allocator pool: not before the tap has read them
                     rec_stream.wait_stream(self._current_stream())
@@ -526,15 +524,28 @@ class HeatMapEngine:
             stream, rec_stream = self._launch_stream()
             nat.check(self.lib.daam_tap_qk_enqueue_many(self.ctx, n, layers.ctypes.data, qp.ctypes.data, kp.ctypes.data,
                                                         dp.ctypes.data))
-            if _before_launch is not None:
-                _before_launch(stream)
-            nat.check(self.lib.daam_tap_flush(self.ctx, stream))
+            self._announce_then_launch(_before_launch, stream)
             if rec_stream is not None:
                 rec_stream.wait_stream(self._current_stream())
             self._window = self.defer_steps
         finally:
             self._drop_recorded()
         return True
+
+    def _announce_then_launch(self, before_launch, stream) -> None:
+        """The recorded calls are in the library's hands: whatever ``before_launch`` does, the launch that consumes (and drops) them
+        must follow -- the Python references to their Q / K are released right after, and entries left pending would be read
+        from freed memory by the next launch.  A failing announcement is re-raised after the launch."""
+        failed = None
+        if before_launch is not None:
+            try:
+                before_launch(stream)
+            except BaseException as e:                         # noqa: BLE001 -- re-raised below
+                failed = e
+        rc = self.lib.daam_tap_flush(self.ctx, stream)
+        if failed is not None:
+            raise failed
+        nat.check(rc)
 
     def _drop_recorded(self) -> None:
         self._rec.clear()

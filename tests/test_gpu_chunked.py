@@ -18,6 +18,7 @@ def _engine(monkeypatch, chunked, n_layers, accumulate, defer):
     """``chunked``: '0' = never (the specialised kernels), '1' = every fp16 layer, None = the default (launches that mix head dims)."""
     from daam_amd import engine as E
     E.release_parked_contexts()                       # the switch is read when a native context is created
+    monkeypatch.setenv('DAAM_TAP_SLAB', '0')           # this file is about the chunked kernel; the slab kernel has tests/test_gpu_slab.py
     if chunked is None:
         monkeypatch.delenv('DAAM_TAP_CHUNKED', raising=False)
     else:

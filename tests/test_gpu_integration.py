@@ -205,28 +205,36 @@ def sd15_stack():
 
 def test_sd15_full_stack_50_steps_three_kernels_side_by_side(sd15_stack, monkeypatch):
     """SD-v1.5 at its real head dims (40 / 80 / 160), a 50-step generation in ONE deferred launch, the whole stack against the
-    reference's processor on the same inputs (120 keys: every one compared).  Default (round 3, second half): a launch that
-    mixes head dims runs as ONE kernel (tap_chunk_kernel, daam_tap_chunk.hip: any head_dim in 64-element chunks).  With
+    reference's processor on the same inputs (120 keys: every one compared).  Default since round 5: ONE slab kernel (daam_tap_slab.hip:
+    640-byte slabs of adjacent heads, whole lines of Q); with DAAM_TAP_SLAB=0 the one chunked kernel of rounds 3-4
+    (tap_chunk_kernel, daam_tap_chunk.hip: any head_dim in 64-element chunks).  With
     DAAM_TAP_CHUNKED=0 it is the three specialised kernels (head_dim 40 -> tap_d64_kernel with zero padding, 80 ->
     tap_wide_kernel<3>, 160 -> tap_wide_kernel<5>), the two small ones on auxiliary streams forked from / joined to the caller's
     stream; then every kernel on the caller's stream (DAAM_NO_SIDE_STREAM=1) and side by side without the start gate
-    (DAAM_NO_START_GATE=1): bit-identical running sums in all four forms."""
+    (DAAM_NO_START_GATE=1): bit-identical running sums in all five forms."""
     from daam_amd import engine as E
     pipe = sd15_stack
     steps = 50
     prompt = 'a photo of a dog chasing a ball'
     sample = list(range(120))
     E.release_parked_contexts()                                  # the environment switches below are read at context creation
-    for var in ('DAAM_NO_SIDE_STREAM', 'DAAM_NO_START_GATE', 'DAAM_TAP_CHUNKED'):
+    for var in ('DAAM_NO_SIDE_STREAM', 'DAAM_NO_START_GATE', 'DAAM_TAP_CHUNKED', 'DAAM_TAP_SLAB'):
         monkeypatch.delenv(var, raising=False)
-    got = _traced_generation(pipe, prompt, steps, sample, defer_steps=64)
+    got = _traced_generation(pipe, prompt, steps, sample, defer_steps=64)      # round 5 default: ONE slab kernel (daam_tap_slab.hip)
     assert len(got['keys']) == 120 and sorted({k[0] for k in got['keys']}) == [1, 2, 4]
     assert got['flush'] == dict(kernels=1, side_streams=0, max_steps=steps, launches=1), got['flush']
     ref = _reference_generation(pipe, prompt, steps, 4096)
     rec = _compare_generation(got, ref, sample, key_ulps=2)
-    _report('sd15', dict(config='SD-v1.5 stack (head_dim 40 / 80 / 160), fp16, 120 keys, %d steps, one flush = one chunked kernel'
+    _report('sd15', dict(config='SD-v1.5 stack (head_dim 40 / 80 / 160), fp16, 120 keys, %d steps, one flush = one slab kernel'
                                 % steps, **rec))
     E.release_parked_contexts()
+    monkeypatch.setenv('DAAM_TAP_SLAB', '0')                     # rounds 3-4: one chunked kernel
+    chunked = _traced_generation(pipe, prompt, steps, sample, defer_steps=64)
+    assert chunked['flush'] == dict(kernels=1, side_streams=0, max_steps=steps, launches=1), chunked['flush']
+    for key in got['raw']:
+        assert torch.equal(got['raw'][key], chunked['raw'][key]), key
+    E.release_parked_contexts()
+    monkeypatch.delenv('DAAM_TAP_SLAB')
     monkeypatch.setenv('DAAM_TAP_CHUNKED', '0')
     three = _traced_generation(pipe, prompt, steps, sample, defer_steps=64)
     assert three['flush'] == dict(kernels=3, side_streams=2, max_steps=steps, launches=1), three['flush']
