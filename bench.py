@@ -64,6 +64,11 @@ WORKLOADS = {
     'sdxl2048': dict(kind='sdxl', latent=256, label='SDXL-base-1.0 topology 2048x2048, 60 layers / 1100 keys', denoise_steps=100,
                      pool_cap=25, min_warm=4),
     'sd15': dict(kind='sd15', latent=64, label='SD-v1.5 topology 512x512, 15 layers / 120 keys'),
+    # the headline's topology in the other dtype modes the reference runs in (dtype-agnostic sums: daam/heatmap.py:153-156)
+    'sdxl1024_bf16': dict(kind='sdxl', latent=128, label='SDXL-base-1.0 topology 1024x1024, 60 layers / 1100 keys, bf16 Q/K and bf16 sums',
+                          dtype='bfloat16'),
+    'sdxl1024_f32acc': dict(kind='sdxl', latent=128, label='SDXL-base-1.0 topology 1024x1024, 60 layers / 1100 keys, fp16 Q/K, f32 sums',
+                            accumulate='float32'),
 }
 
 
@@ -81,7 +86,7 @@ def topology(kind, latent):
     return down + up
 
 
-def make_inputs(layers, pool, device, seed, arena=False):
+def make_inputs(layers, pool, device, seed, arena=False, dtype=torch.float16):
     """``arena``: every Q / K of the pool is a view of ONE allocation (an experiment on what the launch time owes to how the
     recorded tensors are spread over allocator segments -- tools/exp/pool_sweep.py; never the default: a pipeline's Q / K come
     from the caching allocator one tensor at a time)."""
@@ -89,12 +94,12 @@ def make_inputs(layers, pool, device, seed, arena=False):
     big, pos = None, 0
     if arena:
         per_set = sum(2 * side * side * heads * d + 2 * 77 * heads * d for _, heads, side, d in layers)
-        big = torch.empty(pool * per_set, device=device, dtype=torch.float16)
+        big = torch.empty(pool * per_set, device=device, dtype=dtype)
 
     def new(shape):
         nonlocal pos
         if big is None:
-            return torch.randn(*shape, generator=g, device=device, dtype=torch.float16)
+            return torch.randn(*shape, generator=g, device=device, dtype=dtype)
         n = shape[0] * shape[1] * shape[2]
         t = big[pos:pos + n].view(*shape)
         pos += n
@@ -375,10 +380,34 @@ def _respawn_under_launcher(n, shared_device):
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    import importlib.util
+    if importlib.util.find_spec('torch.distributed.run') is not None and os.environ.get('BENCH_NO_TORCHRUN') != '1':
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    # no launcher module (or BENCH_NO_TORCHRUN=1): the same N ranks started by hand -- the env:// rendezvous needs nothing else
+    procs = []
+    for r in range(n):
+        renv = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=renv))
+    rcs = [p.wait() for p in procs]
+    raise SystemExit(next((rc for rc in rcs if rc), 0))
+
+
+def pin_rank_to_cores(local, world):
+    """One slice of the host cores per rank (multi-rank runs): the rank's Python thread, the recorder and the release thread of its
+    engine stay off the other ranks' cores.  Returns the slice as text, or None when the platform / cgroup does not allow it."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // world
+        if per < 2:
+            return None
+        mine = cores[local * per:(local + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return f'{mine[0]}-{mine[-1]} ({len(mine)} of {len(cores)} cores)'
+    except (AttributeError, OSError, ValueError):
+        return None
 
 
 def load_profile(name):
@@ -404,7 +433,7 @@ def load_profile(name):
     return None, f'profiles/{name} was measured on kernel sources {rec.get("csrc_sha")}, this build is {csrc_sha()}'
 
 
-COUNTER_FILES = ('r04_counters.json', 'r03_counters.json', 'r02_counters.json')      # newest first; only one matching this build is used
+COUNTER_FILES = ('r05_counters.json', 'r04_counters.json', 'r03_counters.json', 'r02_counters.json')      # newest first; only one matching this build is used
 
 
 def load_counters():
@@ -431,8 +460,8 @@ def pmc_child(args):
     denoise = args.denoise_steps or wl.get('denoise_steps', 50)
     layers = topology(wl['kind'], wl['latent'])
     pool = args.pool if args.pool > 0 else min(denoise, wl.get('pool_cap', denoise))
-    sets = make_inputs(layers, pool, device, seed=1234)
-    eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=args.accumulate, defer_steps=args.defer,
+    sets = make_inputs(layers, pool, device, seed=1234, dtype=getattr(torch, wl.get('dtype', 'float16')))
+    eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=wl.get('accumulate', args.accumulate), defer_steps=args.defer,
                         defer_bytes=args.defer_bytes if args.defer_bytes > 0 else default_defer_bytes(device))
     calls = call_lists(layers, sets, 64)
     for _ in range(4):
@@ -441,12 +470,16 @@ def pmc_child(args):
     eng.close()
 
 
-def measure_traffic(args, denoise, launches_per_gen, timeout_s=150):
-    """HBM bytes of the tap launch and of the finalize kernels, measured IN THIS RUN: two children of this script
-    (``--pmc-child``: four generations of the same workload) under ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` and ``--pmc
-    WRITE_SIZE`` (separate passes, no other trace domain), converted as /opt/skills/guides/MI355X_MICROARCH.md prescribes for
-    gfx950: bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024.  Per launch = upper median over the kernel's dispatches (the first
-    generation's launch compiles / warms).  Returns (dict or None, note)."""
+_SQ_COUNTERS = ('SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU', 'SQ_INSTS_MFMA')
+
+
+def measure_traffic(args, workload, denoise, launches_per_gen, timeout_s=200, sq=True):
+    """HBM bytes of the tap launch and of the finalize kernels of ``workload`` -- and (``sq``) the issue counters behind
+    ``roofline_issue`` -- measured IN THIS RUN: children of this script (``--pmc-child``: four generations of the workload) under
+    ``rocprofv3 --kernel-trace --pmc FETCH_SIZE``, ``--pmc WRITE_SIZE`` and ``--pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA``
+    (separate passes, no other trace domain), converted as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950:
+    bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024.  Per launch = upper median over the kernel's dispatches (the first generation's
+    launch compiles / warms).  Returns (dict or None, note)."""
     import csv
     import glob
     import shutil
@@ -457,28 +490,37 @@ def measure_traffic(args, denoise, launches_per_gen, timeout_s=150):
     if rp is None:
         return None, 'rocprofv3 is not on PATH'
     vals = {}
-    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+    sq_note = None
+    passes = [('FETCH_SIZE',), ('WRITE_SIZE',)] + ([_SQ_COUNTERS] if sq else [])
+    for counters in passes:
         d = tempfile.mkdtemp(prefix='daam_pmc_', dir='/tmp')
-        cmd = [rp, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__),
-               '--pmc-child', '--workload', args.workload, '--denoise-steps', str(denoise), '--defer', str(args.defer),
+        cmd = [rp, '--kernel-trace', '--pmc', *counters, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__),
+               '--pmc-child', '--workload', workload, '--denoise-steps', str(denoise), '--defer', str(args.defer),
                '--defer-bytes', str(args.defer_bytes), '--accumulate', args.accumulate, '--pool', str(args.pool)]
+        optional = counters is _SQ_COUNTERS                  # the traffic passes are the point; the issue counters are an extra
         try:
             res = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                                  timeout=timeout_s, text=True)
-            if res.returncode != 0:
-                return None, f'rocprofv3 --pmc {counter} child failed (rc {res.returncode}): {res.stderr[-200:]}'
-            fs = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
-            if not fs:
-                return None, f'rocprofv3 --pmc {counter}: no counter_collection.csv'
+            fs = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True) if res.returncode == 0 else []
+            if res.returncode != 0 or not fs:
+                why = (f'rocprofv3 --pmc {" ".join(counters)} child failed (rc {res.returncode}): {res.stderr[-200:]}' if res.returncode != 0
+                       else f'rocprofv3 --pmc {" ".join(counters)}: no counter_collection.csv')
+                if optional:
+                    sq_note = why
+                    continue
+                return None, why
             for row in csv.DictReader(open(fs[0])):
-                if row['Counter_Name'] != counter:
+                if row['Counter_Name'] not in counters:
                     continue
                 for k in _TAP_KERNELS + _FIN_KERNELS:
                     if k in row['Kernel_Name']:
-                        vals.setdefault(k, {}).setdefault(counter, []).append(float(row['Counter_Value']))
+                        vals.setdefault(k, {}).setdefault(row['Counter_Name'], []).append(float(row['Counter_Value']))
                         break
         except subprocess.TimeoutExpired:
-            return None, f'rocprofv3 --pmc {counter} child timed out after {timeout_s} s'
+            if optional:
+                sq_note = f'rocprofv3 --pmc {" ".join(counters)} child timed out after {timeout_s} s'
+                continue
+            return None, f'rocprofv3 --pmc {" ".join(counters)} child timed out after {timeout_s} s'
         finally:
             shutil.rmtree(d, ignore_errors=True)
 
@@ -486,23 +528,88 @@ def measure_traffic(args, denoise, launches_per_gen, timeout_s=150):
         v = sorted(v)
         return statistics.median(v[len(v) // 2:])
 
+    n_gen = 4                                                 # generations a --pmc-child runs (pmc_child)
+
     def kernel_bytes(k):
+        # mean over the kernel's dispatches: a generation of several tap launches has launches of different lengths (SDXL-2048: 64 + 36
+        # steps), and the roofline's bytes_per_launch is their mean too
         cs = vals.get(k, {})
         if 'FETCH_SIZE' not in cs or 'WRITE_SIZE' not in cs:
             return None
-        return dict(read=int(2 * upper_median(cs['FETCH_SIZE']) * 1024), write=int(upper_median(cs['WRITE_SIZE']) * 1024),
-                    dispatches=len(cs['FETCH_SIZE']))
+        return dict(read=int(2 * statistics.fmean(cs['FETCH_SIZE']) * 1024), write=int(statistics.fmean(cs['WRITE_SIZE']) * 1024),
+                    dispatches=len(cs['FETCH_SIZE']), dispatches_per_generation=len(cs['FETCH_SIZE']) / n_gen)
     per = {k: kernel_bytes(k) for k in vals}
     per = {k: v for k, v in per.items() if v}
     tap = [v for k, v in per.items() if k in _TAP_KERNELS]
     fin = [v for k, v in per.items() if k in _FIN_KERNELS]
     if not tap:
         return None, 'no tap kernel in the counter output'
-    return dict(tap_bytes_per_launch=sum(v['read'] + v['write'] for v in tap), finalize_bytes_per_call=sum(v['read'] + v['write'] for v in fin),
-                per_kernel=per, launches_per_generation=launches_per_gen,
-                method='two children of this run under rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); '
-                       'bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 rule of MI355X_MICROARCH.md); upper median over a kernel\'s dispatches; '
-                       'a generation of several tap launches: the figure is the typical (read-modify-write) launch'), None
+    out = dict(tap_bytes_per_launch=sum(v['read'] + v['write'] for v in tap), finalize_bytes_per_call=sum(v['read'] + v['write'] for v in fin),
+               per_kernel=per, launches_per_generation=launches_per_gen,
+               method='children of this run under rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); '
+                      'bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 rule of MI355X_MICROARCH.md); mean over a kernel\'s dispatches '
+                      '(a generation of several tap launches: the mean launch, like bytes_per_launch)')
+
+    def per_simd(names, counter, scale=1.0):
+        ks = [k for k in names if counter in vals.get(k, {})]
+        return round(sum(upper_median(vals[k][counter]) for k in ks) * scale / 1024, 1) if ks else None
+    if sq and any('SQ_ACTIVE_INST_VALU' in vals.get(k, {}) for k in _TAP_KERNELS):
+        # a flush may run several tap kernels side by side: their work adds up on the same 1024 SIMDs; SQ_ACTIVE_INST_VALU counts quad-cycles
+        out['sq'] = dict(tap_valu_busy_cycles_per_simd=per_simd(_TAP_KERNELS, 'SQ_ACTIVE_INST_VALU', 4.0),
+                         tap_valu_insts_per_simd=per_simd(_TAP_KERNELS, 'SQ_INSTS_VALU'), tap_mfma_per_simd=per_simd(_TAP_KERNELS, 'SQ_INSTS_MFMA'),
+                         finalize_valu_busy_cycles_per_simd=per_simd(_FIN_KERNELS, 'SQ_ACTIVE_INST_VALU', 4.0),
+                         finalize_mfma_per_simd=per_simd(_FIN_KERNELS, 'SQ_INSTS_MFMA'),
+                         method='one more child under rocprofv3 --kernel-trace --pmc ' + ' '.join(_SQ_COUNTERS) + '; per SIMD = counter / 1024; '
+                                'VALU-busy cycles = SQ_ACTIVE_INST_VALU (quad-cycles) x 4; upper median over a kernel\'s dispatches')
+    elif sq:
+        out['sq_note'] = sq_note or 'no issue counters in the counter output'
+    return out, None
+
+
+def apply_counters(r, t, why):
+    """Put what measure_traffic() measured in this run into a workload's rooflines (traffic, issue floors); ``t`` None: say why not."""
+    ro, ri, rf, rfi = r['roofline'], r['roofline_issue'], r['roofline_finalize'], r['roofline_finalize_issue']
+    if not t:
+        ro['traffic_in_run_note'] = why
+        return
+    ro.update(traffic=t['tap_bytes_per_launch'], traffic_measured_in_run=True, traffic_source=t['method'], traffic_per_kernel=t['per_kernel'],
+              traffic_over_algorithmic=round(t['tap_bytes_per_launch'] / ro['bytes_per_launch'], 4))
+    if t['finalize_bytes_per_call']:
+        rf.update(traffic=t['finalize_bytes_per_call'], traffic_measured_in_run=True,
+                  traffic_over_algorithmic=round(t['finalize_bytes_per_call'] / rf['bytes_per_launch'], 4))
+    sq = t.get('sq')
+    if not sq:
+        if ri is not None and 'sq_note' in t:
+            ri['counters_in_run_note'] = t['sq_note']
+        return
+    if ri is not None and ri.get('clock') and sq.get('tap_valu_busy_cycles_per_simd'):
+        # two numbers: a FLOOR (the VALU-busy cycles the hardware counted per SIMD: nothing can run faster than its own VALU stream)
+        # and an ESTIMATE that also charges ~10 cycles of closed VALU port per MFMA (tools/gen_ubench_issue.py; an upper estimate of
+        # that block -- launches have been measured up to 4 % under it, so it is not reported as a bound)
+        mhz = ri['clock']['mhz_median_under_load'] * 1e3
+        tap_ms = ri['ms_per_launch']
+        floor_ms = sq['tap_valu_busy_cycles_per_simd'] / mhz
+        est_ms = (sq['tap_valu_busy_cycles_per_simd'] + 10.0 * (sq.get('tap_mfma_per_simd') or 0)) / mhz
+        ri.update(valu_busy_cycles_per_simd=sq['tap_valu_busy_cycles_per_simd'], valu_insts_per_simd=sq.get('tap_valu_insts_per_simd'),
+                  mfma_insts_per_simd=sq.get('tap_mfma_per_simd'), mfma_issue_block_cycles_estimate=10,
+                  floor_ms=round(floor_ms, 4), frac=round(floor_ms / tap_ms, 4), estimate_ms=round(est_ms, 4),
+                  measured_over_estimate=round(tap_ms / est_ms, 4), measured_cycles_per_simd=int(tap_ms * mhz), source=sq['method'],
+                  counters_measured_in_run=True)
+        ri.pop('note', None)
+    if rfi.get('clock') and sq.get('finalize_valu_busy_cycles_per_simd'):
+        n_mfma = sq.get('finalize_mfma_per_simd') or 0
+        mhz = rfi['clock']['mhz_median_under_load'] * 1e3
+        pipe_ms = 32.6 * n_mfma / mhz                         # v_mfma_f32_32x32x16_f16: 32.6 cycles of matrix pipe each (tools/ubench_mfma.hip)
+        valu_ms = sq['finalize_valu_busy_cycles_per_simd'] / mhz
+        fl = max(pipe_ms, valu_ms)
+        rfi.update(valu_busy_cycles_per_simd=sq['finalize_valu_busy_cycles_per_simd'], mfma_insts_per_simd=n_mfma, mfma_pipe_cycles_each=32.6,
+                   model='floor = max(MFMA count x 32.6 cycles of matrix pipe, VALU-busy cycles) per SIMD at the clock sampled in this run',
+                   matrix_pipe_floor_ms=round(pipe_ms, 4), valu_floor_ms=round(valu_ms, 4), floor_ms=round(fl, 4),
+                   frac=round(fl / rfi['ms_per_launch'], 4), source=sq['method'], counters_measured_in_run=True)
+        # ONE fraction for the call: against the larger of its two floors (HBM bytes at the peak; matrix pipe / VALU issue)
+        hbm_ms = rf['bytes_per_launch'] / (HBM_PEAK_GBS * 1e9) * 1e3
+        rf.update(floor_ms=round(max(hbm_ms, fl), 4), floor_kind='hbm' if hbm_ms >= fl else 'matrix pipe / issue',
+                  frac_of_max_floor=round(max(hbm_ms, fl) / rf['ms_per_launch'], 4))
 
 
 def default_defer_bytes(device):
@@ -517,7 +624,7 @@ class Comm:
     device tensors, the production path) or ``gloo`` (functional runs: several ranks on ONE device, where RCCL refuses a
     duplicate GPU; device tensors are staged through the host)."""
 
-    def __init__(self, backend, device):
+    def __init__(self, backend, device, expect_world=None):
         import torch.distributed as dist
         self.dist, self.backend, self.device = dist, backend, device
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -526,6 +633,13 @@ class Comm:
         else:
             dist.init_process_group('gloo')
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        if expect_world is not None and self.world != expect_world:
+            raise SystemExit(f'process group of {self.world} ranks, --gpus {expect_world}: refusing to report a line for another world size')
+        if backend == 'nccl':
+            try:
+                torch.cuda.nccl.version()                       # the collective library must be there BEFORE the timed region needs it
+            except Exception as e:                              # noqa: BLE001
+                raise SystemExit(f'--dist-backend nccl but RCCL is not usable in this process: {e}')
 
     def library(self):
         """What carried the collectives, as the process group reports it (a SCALE record then shows RCCL saw N ranks)."""
@@ -570,9 +684,10 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     layers = topology(wl['kind'], wl['latent'])
     latent_side = 64
     pool = args.pool if args.pool > 0 else min(denoise_steps, wl.get('pool_cap', denoise_steps))
-    sets = make_inputs(layers, pool, device, seed=1234 + rank, arena=getattr(args, 'arena', False))
+    accumulate = wl.get('accumulate', args.accumulate)
+    sets = make_inputs(layers, pool, device, seed=1234 + rank, arena=getattr(args, 'arena', False), dtype=getattr(torch, wl.get('dtype', 'float16')))
     defer_bytes = args.defer_bytes if args.defer_bytes > 0 else default_defer_bytes(device)
-    eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=args.accumulate, defer_steps=args.defer,
+    eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=accumulate, defer_steps=args.defer,
                         defer_bytes=defer_bytes)
     calls = call_lists(layers, sets, latent_side)
     # untimed: the W warm-up generations, plus whatever it takes to reach steady state -- the first call
@@ -618,6 +733,25 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
         return [buf[i] for i in range(n.value)]
     region_tap = history(0, int(round(launches_per_gen * gens)))
     region_fin = history(1, gens)
+    sustained = None
+    if detail and not comm and args.defer > 0 and not getattr(args, 'no_sustained', False):
+        # The driver's timed region is a few dozen milliseconds; the board needs ~0.8 s of back-to-back launches to settle at its power
+        # cap (profiles/r04_power_sclk.txt).  Beside it: >= 2 s of the same generations, the launches timed by the same event ring
+        # (its last <= 256 launches = the settled state).
+        n_s = max(gens, min(20000, int(2.5 / (elapsed / gens)) + 1))
+        note(f'{name}: sustained state, {n_s} generations')
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(n_s):
+            one_generation(eng, calls, denoise_steps)
+        torch.cuda.synchronize()
+        el_s = time.perf_counter() - ts
+        s_tap, s_fin = history(0, 256), history(1, 256)
+        sustained = dict(generations=n_s, seconds=round(el_s, 3), maps_per_s=round(n_s / el_s, 2),
+                         tap_ms_per_launch=round(sum(s_tap) / len(s_tap), 4) if s_tap else None,
+                         finalize_ms=round(sum(s_fin) / len(s_fin), 4) if s_fin else None,
+                         note='back-to-back generations for >= 2 s right after the timed region; launch times = mean over the last '
+                              f'{len(s_tap)} tap launches / {len(s_fin)} finalize calls (HIP events, read afterwards)')
     nat.check(eng.lib.daam_profile_enable(eng.ctx, 0))
     if comm:
         elapsed = comm.max(elapsed)
@@ -632,9 +766,9 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
         return None
 
     note(f'{name}: {world * gens / elapsed:.1f} maps/s; kernel measurements')
-    acc_bytes = 2 if args.accumulate == 'exact' else 4
-    out = dict(label=wl['label'], elapsed=elapsed, gens=gens, denoise_steps=denoise_steps,
-               value=world * gens / elapsed, ms_per_step=elapsed / gens * 1e3, keys=sum(h for _, h, _, _ in layers))
+    acc_bytes = 2 if accumulate == 'exact' else 4
+    out = dict(label=wl['label'], elapsed=elapsed, gens=gens, denoise_steps=denoise_steps, accumulate=accumulate,
+               value=world * gens / elapsed, ms_per_step=elapsed / gens * 1e3, keys=sum(h for _, h, _, _ in layers), sustained=sustained)
     # steps one tap launch covers: the step window, or fewer when the recorded Q / K reach the engine's
     # byte budget (a launch is then forced at the next step boundary)
     step_bytes = sum(q.numel() * q.element_size() + k.numel() * k.element_size() for q, k in sets[0])
@@ -686,7 +820,7 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
         out['tap_ms_per_generation'] = tap_ms_avg * launches_per_gen
     achieved = bytes_launch / (tap_ms_avg * 1e-3) / 1e9
     survey_bytes = spl * (qk_bytes + 2 * acc_total) if args.defer > 0 else bytes_launch   # RMW per step
-    key = f'{name}:defer{spl}:{args.accumulate}'
+    key = f'{name}:defer{spl}:{accumulate}'
     prof, prof_note = load_counters()
     rec = (prof or {}).get('workloads', {}).get(key)
     if rec and rec.get('tap_kernels_per_launch', flush['kernels']) != flush['kernels']:
@@ -697,7 +831,7 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     traffic = rec.get('tap_bytes_per_launch') if rec else None
     tap_kernel = ('tap_d64_kernel (16x16x32 MFMA tiles, head_dim 64)' if wl['kind'] == 'sdxl'
                   else 'tap_slab_kernel (head_dim 40 / 80 / 160: 640-byte slabs of adjacent heads, whole 128-byte lines of Q, every layer in ONE launch)'
-                  if flush['kernels'] == 1 and os.environ.get('DAAM_TAP_SLAB', '1') != '0' and args.accumulate in ('exact', 'float32')
+                  if flush['kernels'] == 1 and os.environ.get('DAAM_TAP_SLAB', '1') != '0'
                   else 'tap_chunk_kernel (head_dim 40 / 80 / 160 in 64-element chunks, every layer in ONE launch)' if flush['kernels'] == 1
                   else 'tap_d64_kernel (head_dim 40) + tap_wide_kernel<3|5> (head_dim 80 / 160), one flush = 3 kernels side by side')
     out['roofline'] = dict(bound='hbm', kernel=tap_kernel,
@@ -756,7 +890,7 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     fin_gbs = fin_bytes / (fin_ms * 1e-3) / 1e9
     fin_kernel = {'sdxl1024': 'finalize_up32_pipe_kernel (x2 class software-pipelined on the matrix cores; the same-size keys ride along)',
                   'sdxl2048': 'finalize_down2 (128 -> 64) + finalize_same_kernel',
-                  'sd15': 'finalize_up32_pipe_kernel (x2 + same-size keys) + finalize_up_kernel<16>'}[name]
+                  'sd15': 'finalize_up32_pipe_kernel (x2 + same-size keys) + finalize_up_kernel<16>'}.get(name, 'the x2 / same-size class kernels of this sum dtype')
     fin_kernel += ('; key tables cached on the device, output cleared by the upload kernel of the tap launch in front (daam_finalize_prepare, ABI v5): '
                    'the timed call is the class kernel(s) only')
     fin_issue = dict(bound='matrix-pipe / issue', kernel=fin_kernel, clock=fin_clock, ms_per_launch=round(fin_ms, 4))
@@ -809,6 +943,8 @@ def main():
     ap.add_argument('--no-pmc', action='store_true', help='skip the in-run HBM-traffic measurement (two short children under rocprofv3 --pmc)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short legs of the other single-GPU BASELINE configurations')
+    ap.add_argument('--no-dtype-legs', action='store_true', help='skip the bf16 and f32-sums legs of the headline topology')
+    ap.add_argument('--no-sustained', action='store_true', help='skip the >= 2 s sustained-state leg behind the timed region')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help='process-group backend of a multi-rank run: nccl = RCCL over xGMI (production); gloo = functional runs')
     ap.add_argument('--shared-device', action='store_true',
@@ -831,7 +967,8 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    comm = Comm(args.dist_backend, device) if world > 1 else None
+    affinity = pin_rank_to_cores(local if not args.shared_device else rank, world) if world > 1 else None
+    comm = Comm(args.dist_backend, device, expect_world=args.gpus) if world > 1 else None
 
     denoise = args.denoise_steps or WORKLOADS[args.workload].get('denoise_steps', 50)
     main_rec = run_workload(args.workload, denoise, args.steps, args.warmup, device, args, comm=comm, rank=rank, world=world)
@@ -840,16 +977,8 @@ def main():
     if rank == 0:
         r = main_rec
         if world == 1 and not args.no_pmc:
-            note('HBM traffic: two children under rocprofv3 --pmc')
-            t, why = measure_traffic(args, denoise, r['roofline']['launches_per_generation'])
-            if t:
-                r['roofline'].update(traffic=t['tap_bytes_per_launch'], traffic_measured_in_run=True, traffic_source=t['method'],
-                                     traffic_per_kernel=t['per_kernel'],
-                                     traffic_over_algorithmic=round(t['tap_bytes_per_launch'] / r['roofline']['bytes_per_launch'], 4))
-                if t['finalize_bytes_per_call']:
-                    r['roofline_finalize'].update(traffic=t['finalize_bytes_per_call'], traffic_measured_in_run=True)
-            else:
-                r['roofline']['traffic_in_run_note'] = why
+            note('HBM traffic + issue counters: children under rocprofv3 --pmc')
+            apply_counters(r, *measure_traffic(args, args.workload, denoise, r['roofline']['launches_per_generation']))
         gpu_ms_per_gen = r['tap_ms_per_generation'] + r['fin_ms']
         extra = dict(
             extraction_overhead_ms_per_denoise_step=round(r['ms_per_step'] / denoise, 4),
@@ -863,15 +992,26 @@ def main():
         if world == 1 and not args.no_other_configs and args.workload == 'sdxl1024':
             # the other single-GPU configurations of BASELINE.json, short legs (their parity: tests/test_gpu_integration.py)
             others = {}
-            for name, g, wu in (('sd15', 20, 5), ('sdxl2048', 5, 2)):
+            legs = [('sd15', 20, 5), ('sdxl2048', 5, 2)]
+            if not args.no_dtype_legs:
+                legs += [('sdxl1024_bf16', 20, 5), ('sdxl1024_f32acc', 20, 5)]
+            for name, g, wu in legs:
                 ds = WORKLOADS[name].get('denoise_steps', 50)
                 o = run_workload(name, ds, g, wu, device, args, detail=False)
-                others[name] = dict(config=f'{o["label"]}, {ds} denoising steps, 77 tokens, CFG batch 2, fp16 Q/K',
+                if not args.no_pmc:
+                    note(f'{name}: HBM traffic + issue counters under rocprofv3 --pmc')
+                    apply_counters(o, *measure_traffic(args, name, ds, o['roofline']['launches_per_generation'], sq=name in ('sd15', 'sdxl2048')))
+                dt = {'bfloat16': 'bf16'}.get(WORKLOADS[name].get('dtype'), 'fp16')
+                others[name] = dict(config=f'{o["label"]}, {ds} denoising steps, 77 tokens, CFG batch 2, {dt} Q/K, accumulate={o["accumulate"]}',
                                     value=round(o['value'], 2), unit='maps/s', generations=g, warmup=wu,
                                     ms_per_step=round(o['ms_per_step'], 3),
                                     gpu_bound_maps_per_s=round(1e3 / (o['tap_ms_per_generation'] + o['fin_ms']), 1),
                                     roofline=o['roofline'], roofline_issue=o['roofline_issue'],
-                                    roofline_finalize=o['roofline_finalize'])
+                                    roofline_finalize=o['roofline_finalize'], roofline_finalize_issue=o['roofline_finalize_issue'])
+            # the dtype legs against the headline: tap launch time relative to the fp16 / fp16-sums launch of THIS run
+            for name in ('sdxl1024_bf16', 'sdxl1024_f32acc'):
+                if name in others:
+                    others[name]['tap_ms_over_fp16_headline'] = round(others[name]['roofline']['ms_per_launch'] / r['roofline']['ms_per_launch'], 4)
             extra['other_configs'] = others
         if not args.no_integrated and world == 1 and args.workload == 'sdxl1024':
             note('integrated overhead')
@@ -899,6 +1039,11 @@ def main():
             'config': {'workload': f'{r["label"]}, {denoise} denoising steps, 77 tokens, CFG batch 2, fp16 Q/K',
                        'accumulate': args.accumulate, 'defer_steps': r['steps_per_launch'], 'parallelism': f'prompt-shard x{world}',
                        'generations_per_rank': args.steps,
+                       'baseline_config': ('BASELINE.json configs[3]: SDXL-base-1.0 1024x1024, 50 steps, batch=32 prompts sharded 8xMI355X (RCCL gather)'
+                                           if (world == 8 and world * args.steps == 32 and args.workload == 'sdxl1024' and denoise == 50) else
+                                           'BASELINE.json configs[2] per rank' + (f' x {world} ranks (prompt shards; configs[3] is this at --gpus 8 --steps 4)' if world > 1 else '')
+                                           if args.workload == 'sdxl1024' else None),
+                       'rank_cpu_affinity': affinity,
                        'collective': None if world == 1 else f'all_gather of the final [{args.steps}, 77, 64, 64] fp32 maps per rank over '
                                                               f'{args.dist_backend}' + (' -- ALL RANKS ON ONE DEVICE (functional run, not a '
                                                                                         'scaling measurement)' if args.shared_device else ''),
@@ -906,6 +1051,14 @@ def main():
                        'collective_library': comm.library() if comm else None},
             'roofline': r['roofline'], 'cpu_baseline': cpu,
         }
+        if r.get('sustained'):
+            su = r['sustained']
+            out['sustained'] = su
+            out['sustained_maps_per_s'] = su['maps_per_s']
+            out['sustained_tap_ms'] = su['tap_ms_per_launch']
+            if su['tap_ms_per_launch']:
+                out['roofline']['sustained_ms_per_launch'] = su['tap_ms_per_launch']
+                out['roofline']['sustained_frac'] = round(r['roofline']['bytes_per_launch'] / (su['tap_ms_per_launch'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out.update(extra)
     if comm:
         comm.close()

@@ -210,6 +210,8 @@ struct DaamCtx {
     std::vector<char> fin_tab_host;   // the bytes d_fin_tab holds (when fin_tab_valid)
     bool fin_tab_valid = false;
     hipStream_t fin_tab_stream = nullptr;   // the stream its upload and its readers were enqueued on
+    int tap_q2 = 0;                   // DAAM_TAP_Q2=1: eight-wave head_dim-64 launches request half of every Q tile two steps ahead (round 5: built on the verdict's
+                                      // advice, bit-identical, measured 1.3 % SLOWER on the headline -- 491-493 against 498 maps/s alternating on one box -- so it is opt-in)
     int no_w8 = 0;                    // debugging / A-B: DAAM_TAP_W8=0 (head_dim-64 launches on 4-wave workgroups of 128 pixels instead of 8-wave / 256)
     int no_fin_cache = 0;             // debugging / A-B: DAAM_NO_FIN_CACHE=1 (tables through the ring + zeroing in every call)
     // daam_finalize_prepare: the output buffer the next daam_finalize accumulates into has been zeroed already (prep_*), or is to
@@ -251,12 +253,19 @@ struct DaamCtx {
     unsigned started_target = 0;       // ... and how many the host has launched
     unsigned* gate_timeouts = nullptr; // pinned, device-mapped: gates that gave up after their 200 us (the side kernels were NOT running beside them)
     unsigned* gate_timeouts_dev = nullptr;
-    int no_start_gate = 0;             // debugging / A-B: DAAM_NO_START_GATE=1
+    int no_start_gate = 0;             // DAAM_NO_START_GATE=1 (debugging / A-B), or a failed flush left counter and target in disagreement
+    unsigned gate_timeouts_seen = 0;   // value of *gate_timeouts when the previous gated flush was enqueued
+    int gate_strikes = 0;              // consecutive gated flushes whose gate timed out
+    long long gate_off_until = 0;      // n_flushes at which a gate that was dropped for timing out is tried again (0 = in use)
+    bool gate_prev_gated = false;      // the previous multi-kernel flush carried a gate
+    bool gate_said = false;
     int no_side_stream = 0;
 
     int force_generic = 0;
     int fast_exp = 0;
     int no_d64 = 0;
+    int slab_tail_pct = 25;           // DAAM_SLAB_TAIL: percent of a head_dim-40 layer's pixels the slab kernel takes in 16-pixel tiles at the end of the launch
+                                      // (SD-v1.5, alternating on one box: 0 -> 2390, 25 -> 2415, 50 -> 2316, 100 -> 2204 maps/s: half-size units cost K traffic)
     int tap_slab = 1;                 // tap_slab_kernel (daam_tap_slab.hip): deferred fp16 layers of head_dim 40 / 80 / 160 in 640-byte slabs of adjacent heads
                                       // (whole 128-byte lines of Q: SD-v1.x); DAAM_TAP_SLAB=0 leaves them to the kernels below
     int tap_chunked = 2;              // tap_chunk_kernel (fp16 layers of any head_dim, one kind of workgroup): 2 = for deferred launches that
@@ -427,12 +436,16 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->no_paired_finalize = npf && npf[0] == '1';
     const char* w8 = getenv("DAAM_TAP_W8");
     c->no_w8 = w8 && w8[0] == '0';
+    const char* q2 = getenv("DAAM_TAP_Q2");
+    c->tap_q2 = q2 && q2[0] == '1';
     const char* nfc = getenv("DAAM_NO_FIN_CACHE");
     c->no_fin_cache = nfc && nfc[0] == '1';
     const char* n16 = getenv("DAAM_NO_D64");            // debugging: 32x32-tile kernel also for head_dim 64
     c->no_d64 = n16 && n16[0] == '1';
     const char* nss = getenv("DAAM_NO_SIDE_STREAM");        // debugging / A-B: every tap kernel of a flush on the caller's stream
     c->no_side_stream = nss && nss[0] == '1';
+    const char* stl = getenv("DAAM_SLAB_TAIL");
+    if (stl && stl[0]) c->slab_tail_pct = std::max(0, std::min(100, atoi(stl)));
     const char* tsl = getenv("DAAM_TAP_SLAB");
     c->tap_slab = !(tsl && tsl[0] == '0');
     const char* tck = getenv("DAAM_TAP_CHUNKED");           // daam_tap_chunk.hip: unset = launches that mix head dims, 1 = always, 0 = never
@@ -629,6 +642,9 @@ static void fill_layer(const DaamCtx* c, const Layer& l, const DaamQKDesc& d, in
     t->round_logits = d.round_logits;
     t->scale = d.scale;
     t->fresh = l.dirty ? 0 : 1;
+    t->px_begin = 0;
+    t->px_end = d.hw;
+    t->tile_px = tile_pixels;
     t->q_sb = d.q_stride_b; t->q_sh = d.q_stride_h; t->q_sp = d.q_stride_p;
     t->k_sb = d.k_stride_b; t->k_sh = d.k_stride_h; t->k_st = d.k_stride_t;
     (void)c;
@@ -970,6 +986,27 @@ int daam_tap_flush(DaamCtx* c, void* stream)
                 if (kind[i] == kd) rc = ensure_zeroed(c->layers[order[i]], s);
             if (rc) break;
         }
+        // table entries of this kind: one per layer -- except that the slab kernel (71) may take the LAST pixels of a head_dim-40 layer as a second
+        // entry with 16-pixel tiles (see below)
+        struct Ent { size_t i; int rank, px_begin, px_end, tile; };
+        std::vector<Ent> ents;
+        // slab kernel: the layers segment by segment (one cost per workgroup each): head_dim 160 first (few, light workgroups with the longest
+        // step chains), 40 (the bulk), 80 (short chains), and last the TAIL of the head_dim-40 layers in half-size workgroups: 2.2 rounds of
+        // indivisible 50-step chains leave a third of the chip idle for the last 100 us of the launch; half-length units empty it more evenly
+        // (DAAM_SLAB_TAIL = percent of a head_dim-40 layer's pixels that go there; bit-identical sums either way).  Every XCD takes an eighth of
+        // each segment.
+        auto seg_rank = [](int d) { return d == 160 ? 0 : d == 40 ? 1 : 2; };
+        for (size_t i = 0; i < order.size(); ++i) {
+            if (kind[i] != kd) continue;
+            const DaamQKDesc& d0 = per[i][0]->d;
+            if (kd != 71) { ents.push_back({i, 0, 0, d0.hw, tile}); continue; }
+            const int r = seg_rank(d0.head_dim);
+            const int tail_px = (r == 1 && d0.hw >= 64) ? (int)((int64_t)d0.hw * c->slab_tail_pct / 100 / 32) * 32 : 0;
+            if (d0.hw - tail_px > 0) ents.push_back({i, r, 0, d0.hw - tail_px, tile});
+            if (tail_px > 0) ents.push_back({i, 3, d0.hw - tail_px, d0.hw, tile / 2});
+        }
+        if (kd == 71) std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.rank < b.rank; });
+        n_layers = ents.size();
         const size_t bytes_layers = n_layers * sizeof(TapLayer), bytes = bytes_layers + n_ptrs * sizeof(TapPtr);
         size_t off = 0;
         hipError_t e = c->ring.alloc(bytes, &off);
@@ -977,27 +1014,27 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         TapLayer* hl = reinterpret_cast<TapLayer*>(c->ring.host + off);
         TapPtr* hp = reinterpret_cast<TapPtr*>(c->ring.host + off + bytes_layers);
         int wg = 0, ptr = 0, max_d = 0, min_d = 1 << 30, all_round = 1;
+        std::vector<int> ptr_of(order.size(), -1);             // a layer's step pointers are written once, both of its entries point at them
+        for (size_t i = 0; i < order.size(); ++i) {
+            if (kind[i] != kd) continue;
+            ptr_of[i] = ptr;
+            for (auto* p : per[i]) { hp[ptr].q = p->q; hp[ptr].k = p->k; ++ptr; }
+        }
         size_t j = 0;
-        std::vector<size_t> sel;
-        for (size_t i = 0; i < order.size(); ++i)
-            if (kind[i] == kd) sel.push_back(i);
-        // slab kernel: the layers segment by segment (one head_dim = one cost per workgroup each): head_dim 160 first (few, light workgroups
-        // with the longest step chains), 40 (the bulk), 80 last (the short chains fill the tail); every XCD takes an eighth of each segment
         int seg_begin[5] = {0, 0, 0, 0, 0}, n_seg = 0;
-        auto seg_rank = [](int d) { return d == 160 ? 0 : d == 40 ? 1 : 2; };
-        if (kd == 71)
-            std::stable_sort(sel.begin(), sel.end(), [&](size_t a, size_t b) { return seg_rank(per[a][0]->d.head_dim) < seg_rank(per[b][0]->d.head_dim); });
         int last_rank = -1;
-        for (size_t i : sel) {
-            const auto& v = per[i];
-            fill_layer(c, c->layers[order[i]], v[0]->d, tile, &hl[j]);
+        for (const Ent& en : ents) {
+            const auto& v = per[en.i];
+            fill_layer(c, c->layers[order[en.i]], v[0]->d, en.tile, &hl[j]);
             hl[j].wg_begin = wg;
             hl[j].n_steps = (int)v.size();
-            hl[j].ptr_begin = ptr;
-            for (auto* p : v) { hp[ptr].q = p->q; hp[ptr].k = p->k; ++ptr; }
+            hl[j].ptr_begin = ptr_of[en.i];
+            hl[j].px_begin = en.px_begin;
+            hl[j].px_end = en.px_end;
+            hl[j].tile_px = en.tile;
+            hl[j].tiles_per_head = (en.px_end - en.px_begin + en.tile - 1) / en.tile;
             if (kd == 71) {
-                const int r = seg_rank(v[0]->d.head_dim);
-                if (r != last_rank) { seg_begin[n_seg++] = wg; last_rank = r; }
+                if (en.rank != last_rank) { seg_begin[n_seg++] = wg; last_rank = en.rank; }
                 wg += hl[j].heads_kept / tap_slab_heads(v[0]->d.head_dim) * hl[j].tiles_per_head;   // tiles_per_head = tiles per slab
             } else {
                 wg += hl[j].heads_kept * hl[j].tiles_per_head;
@@ -1067,12 +1104,26 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     // resident -- only for the kernels that carry the counter (the MFMA kinds)
     // a gate of an earlier flush ran into its timeout: the auxiliary streams do not run beside the caller's here (one hardware queue,
     // GPU_MAX_HW_QUEUES) -- every gated flush would pay the 200 us for nothing, so the context stops using it (said once)
-    if (!c->no_start_gate && c->gate_timeouts && *reinterpret_cast<volatile unsigned*>(c->gate_timeouts) != 0) {
-        c->no_start_gate = 1;
-        fprintf(stderr, "libdaam_hip: the start gate of a multi-kernel tap launch timed out (side streams not concurrent with the caller's "
-                        "stream); gate disabled for this context\n");
+    // A gate that runs into its 200 us timeout means the side kernels were NOT running beside the caller's stream at that moment (one
+    // hardware queue, GPU_MAX_HW_QUEUES; or another process held the GPU).  One such delay must not cost the context its gate for good:
+    // it is dropped after three CONSECUTIVE gated flushes that timed out, said once, and tried again 64 flushes later.
+    if (forked && c->gate_timeouts) {
+        const unsigned now = *reinterpret_cast<volatile unsigned*>(c->gate_timeouts);
+        if (c->gate_off_until && c->n_flushes >= c->gate_off_until) { c->gate_off_until = 0; c->gate_strikes = 0; c->gate_timeouts_seen = now; }
+        if (!c->gate_off_until && c->gate_prev_gated) {
+            c->gate_strikes = now != c->gate_timeouts_seen ? c->gate_strikes + 1 : 0;
+            c->gate_timeouts_seen = now;
+            if (c->gate_strikes >= 3) {
+                c->gate_off_until = c->n_flushes + 64;
+                if (!c->gate_said) {
+                    c->gate_said = true;
+                    fprintf(stderr, "libdaam_hip: the start gate of three multi-kernel tap launches in a row timed out (side streams not concurrent with "
+                                    "the caller's stream); the gate rests for 64 launches\n");
+                }
+            }
+        }
     }
-    bool gate = forked && !main_first && !c->no_start_gate && c->d_started;
+    bool gate = forked && !main_first && !c->no_start_gate && !c->gate_off_until && c->d_started;
     for (size_t i = 0; i < prepared.size(); ++i)
         if (i != main_idx && !prepared[i].kd) gate = false;
     unsigned gate_wgs = 0;
@@ -1090,7 +1141,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             if (ge != hipSuccess) { rc = fail((int)ge, "start gate: %s", hipGetErrorString(ge)); break; }
         }
         int grid = 0;
-        hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, pr.w8 ? 1 : 0, ks, &grid, &c->last_lds[0])
+        hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, pr.w8 ? (c->tap_q2 ? 2 : 1) : 0, ks, &grid, &c->last_lds[0])
                      : (pr.kd == 67 || pr.kd == 69) ? launch_tap_wide(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
                      : pr.kd == 70 ? launch_tap_chunk(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d != pr.max_d, ks, &grid, &c->last_lds[0])
                      : pr.kd == 71 ? launch_tap_slab(pr.L, c->acc_dtype, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
@@ -1110,6 +1161,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     // a flush that failed part-way may have announced side workgroups that never started: counter and target would disagree for
     // good (every later gate a silent no-op or a full timeout), so the context stops gating
     if (rc && gate) c->no_start_gate = 1;
+    if (forked) c->gate_prev_gated = gate && gate_wgs != 0;
     // join (after the main kernel is enqueued): the caller's stream continues when every side kernel is done
     for (int i = 0; i < n_side; ++i)
         if (hipStreamWaitEvent(s, c->aux_join[i], 0) != hipSuccess) rc = rc ? rc : fail(DAAM_E_STATE, "stream join failed");
@@ -1588,8 +1640,16 @@ int daam_profile_enable(DaamCtx* c, int on)
         for (int which = 0; which < 2; ++which)
             for (int end = 0; end < 2; ++end)
                 if (c->hist_ev[which][end].empty()) {
-                    c->hist_ev[which][end].resize(DaamCtx::kProfHist, nullptr);
-                    for (auto& ev : c->hist_ev[which][end]) HIP_TRY(hipEventCreate(&ev));
+                    std::vector<hipEvent_t> ring(DaamCtx::kProfHist, nullptr);
+                    hipError_t e = hipSuccess;
+                    for (auto& ev : ring)
+                        if ((e = hipEventCreate(&ev)) != hipSuccess) break;
+                    if (e != hipSuccess) {                     // never leave a ring with null events behind: prof_event() would hand them out
+                        for (auto ev : ring)
+                            if (ev) (void)hipEventDestroy(ev);
+                        return fail((int)e, "profile event ring: %s", hipGetErrorString(e));
+                    }
+                    c->hist_ev[which][end] = std::move(ring);
                 }
         c->hist_count[0] = c->hist_count[1] = 0;
     }
@@ -1617,6 +1677,14 @@ int daam_profile_last_ms(DaamCtx* c, int which, float* ms)
 {
     if (!c || !ms || which < 0 || which > 1) return fail(DAAM_E_INVALID, "bad argument");
     if (!c->prof_ev[which][0]) return fail(DAAM_E_STATE, "profiling was never enabled");
+    DeviceGuard on_device(c);
+    if (c->profile == 2) {                                     // the launches record into the ring: the newest slot, not a stale prof_ev pair
+        if (c->hist_count[which] <= 0 || c->hist_ev[which][0].empty()) return fail(DAAM_E_STATE, "no launch of kind %d since daam_profile_enable(ctx, 2)", which);
+        const size_t slot = (size_t)((c->hist_count[which] - 1) % DaamCtx::kProfHist);
+        HIP_TRY(hipEventSynchronize(c->hist_ev[which][1][slot]));
+        HIP_TRY(hipEventElapsedTime(ms, c->hist_ev[which][0][slot], c->hist_ev[which][1][slot]));
+        return 0;
+    }
     HIP_TRY(hipEventSynchronize(c->prof_ev[which][1]));
     HIP_TRY(hipEventElapsedTime(ms, c->prof_ev[which][0], c->prof_ev[which][1]));
     return 0;

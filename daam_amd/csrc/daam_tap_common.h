@@ -46,6 +46,7 @@ __device__ __forceinline__ void load_layer(const DAAM_GLOBAL TapLayer* g, TapLay
     out->round_logits = g->round_logits; out->scale = g->scale; out->fresh = g->fresh;
     out->q_sb = g->q_sb; out->q_sh = g->q_sh; out->q_sp = g->q_sp;
     out->k_sb = g->k_sb; out->k_sh = g->k_sh; out->k_st = g->k_st;
+    out->px_begin = g->px_begin; out->px_end = g->px_end; out->tile_px = g->tile_px;
 }
 
 constexpr float kMasked = -1.0e30f;    // logit of the padding tokens: exp() underflows to exactly 0

@@ -26,6 +26,7 @@
 // lookup -- 0.67 lookups per cycle per CU and a read-tag-conflict stall in 20 % of the cycles
 // (TCP_TOTAL_CACHE_ACCESSES, TCP_READ_TAGCONFLICT_STALL_CYCLES; profiles/r02_tap_tcp.txt).
 #include "daam_tap16_softmax.h"
+#include <type_traits>
 
 // cache policy of the Q fetches (every Q row is read exactly once per launch): 0 = default, 2 = non-temporal (A/B: -DDAAM_TAP_Q_AUX=2)
 #ifndef DAAM_TAP_Q_AUX
@@ -76,8 +77,9 @@ constexpr int kTapQTile = 32 * kTapRow;             // 4096: one wave's 32 pixel
 constexpr int kTapQOff = 2 * kTapKBuf;              // Q tiles of the four waves follow the two K buffers
 
 // WAVES = waves per workgroup: 4 (128 pixels) or 8 (256 pixels of one head, ONE K tile for twice the pixels: see DAAM_TAP_W8)
-template <typename ACC_T, int WAVES = 4> constexpr size_t tap_d64_lds_bytes() {
-    const size_t kb = 2 * (size_t)kTapKBuf + WAVES * (size_t)kTapQTile, st = (size_t)kTok * (32 * WAVES) * sizeof(ACC_T);
+// Q2 (eight waves only): a second buffer for the FIRST half (16 rows) of every wave's Q tile -- see the kernel
+template <typename ACC_T, int WAVES = 4, bool Q2 = false> constexpr size_t tap_d64_lds_bytes() {
+    const size_t kb = 2 * (size_t)kTapKBuf + WAVES * (size_t)kTapQTile + (Q2 ? WAVES * (size_t)kTapQTile / 2 : 0), st = (size_t)kTok * (32 * WAVES) * sizeof(ACC_T);
     return (kb > st ? kb : st) + (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*) + (DAAM_TAP_TOUCH ? 256 : 0);     // fp16 sums: 37888 -> 4 workgroups per CU
 }
 
@@ -86,17 +88,24 @@ __device__ __forceinline__ constexpr int swz_chunk(int row, int chunk) { return 
 
 // FULL64: every layer of the launch has head_dim == 64 (SDXL): the zero-padding selects of the head_dim < 64 case (8 VALU per
 // wave-step) are compiled out
-template <typename IN, typename ACC_T, bool FAST_EXP, bool FULL64, int WAVES = 4>
+// Q2 (round 5; WAVES == 8, DMA path): the two workgroups of a CU use 106 of its 160 KB of LDS, and what bounds the launch is its data
+// path -- ONE Q tile per wave in flight for ~0.9 of a step (LABNOTES R4.6).  With Q2 the first 16 pixel rows of a wave's tile have two
+// buffers and are requested TWO steps ahead (into the buffer whose operands were just read), the other 16 rows one step ahead as
+// before: 1.5 tiles in flight per wave at no VALU or register cost (LDS-DMA; round 4's register-set version paid for itself in
+// issue slots).  The step loop is unrolled by two so that the buffer of a step is an immediate offset.  69 KB of LDS, still two
+// workgroups per CU.
+template <typename IN, typename ACC_T, bool FAST_EXP, bool FULL64, int WAVES = 4, bool Q2 = false>
 __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && !IN::kBf16)) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
 {
+    static_assert(!Q2 || (WAVES == 8 && FULL64 && DAAM_TAP_DMA && DAAM_TAP_EARLY_DMA && !DAAM_TAP_TOUCH), "Q2: the eight-wave DMA form only");
     constexpr int NT = 64 * WAVES;                            // threads per workgroup
     constexpr int TILE = 32 * WAVES;                          // pixels per workgroup (the host sizes tiles_per_head with it)
     static_assert(WAVES == 4 || (WAVES == 8 && FULL64 && DAAM_TAP_DMA), "eight waves: head_dim-64 launches on the DMA path only");
     constexpr int KCH = (kTok * 8 + 255) / 256;               // 16-B K pieces per thread per step (3)
     constexpr int VEC = AccVec<ACC_T>::kPerVec;
     constexpr int PPR = TILE / VEC;
-    constexpr size_t kPtrOff = tap_d64_lds_bytes<ACC_T, WAVES>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*) - (DAAM_TAP_TOUCH ? 256 : 0);
-    [[maybe_unused]] constexpr size_t kTouchOff = tap_d64_lds_bytes<ACC_T, WAVES>() - 256;     // DAAM_TAP_TOUCH: 256 bytes nobody reads
+    constexpr size_t kPtrOff = tap_d64_lds_bytes<ACC_T, WAVES, Q2>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*) - (DAAM_TAP_TOUCH ? 256 : 0);
+    [[maybe_unused]] constexpr size_t kTouchOff = tap_d64_lds_bytes<ACC_T, WAVES, Q2>() - 256;     // DAAM_TAP_TOUCH: 256 bytes nobody reads
 
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* kbuf = smem;                               // [2][kTapKBuf], then the four waves' Q tiles
@@ -216,6 +225,7 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
     for (int i = 0; i < 4; ++i) q_s[i] = 8 * i < q_rows_in ? (unsigned)i * q_step8 : 0u;
     // LDS write position of piece i: row (q_row + 8 i), swizzle key ((lane >> 4) + 4 i) & 7 = (lane >> 4) ^ 4 (i & 1)
     unsigned char* qtile = kbuf + kTapQOff + wave * kTapQTile;
+    [[maybe_unused]] unsigned char* qalt = kbuf + kTapQOff + WAVES * kTapQTile + wave * (kTapQTile / 2);   // Q2: second buffer of rows 0..15
     const int q_wr = q_row * kTapRow + ((q_chunk ^ (lane >> 4)) << 4);
     // operand reads: row l&15 of a 16-row tile, chunk 4 ks + (l >> 4); the same offset serves K (A) and Q (B)
     const int f_rd = j * kTapRow + swz_chunk(j, h);            // k-step 1: ^ 64
@@ -293,6 +303,19 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(qtile + i * 1024), 16, qd_src[i & 1], q_s[i], 0, DAAM_TAP_Q_AUX);
     };
+    // Q2: rows 16..31 of step s (into the tile), rows 0..15 of step s (into buffer `alt`: the tile's first half or the second buffer)
+    [[maybe_unused]] auto dma_q_hi = [&](int s) {
+        const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
+#pragma unroll
+        for (int i = 2; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(qtile + i * 1024), 16, qd_src[i & 1], q_s[i], 0, DAAM_TAP_Q_AUX);
+    };
+    [[maybe_unused]] auto dma_q_lo = [&](int s, bool alt) {
+        const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)((alt ? qalt : qtile) + i * 1024), 16, qd_src[i & 1], q_s[i], 0, DAAM_TAP_Q_AUX);
+    };
 #endif
 #if DAAM_TAP_TOUCH
     const unsigned q_touch = (unsigned)__builtin_amdgcn_readfirstlane(
@@ -302,7 +325,8 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
     // one denoising step: logits of step s from the K and Q tiles in LDS, then the fetches of the next step (head_dim 64: by DMA
     // into the other K buffer / this wave's own Q tile, whose reads are behind it; head_dim < 64: step s + 1 from the staging
     // registers into LDS and the request for step s + 2), softmax + accumulate of the two pixel groups
-    auto step = [&](int s) {
+    auto step = [&](int s, auto parity) {
+        [[maybe_unused]] constexpr bool kAlt = decltype(parity)::value;        // Q2: rows 0..15 of this step sit in the second buffer
 #if DAAM_TAP_TOUCH
         // bare barrier: __syncthreads() carries a fence, for which hipcc waits vmcnt(0) -- the touches would be waited for after all.
         // LDS visibility: this wave's DMAs were waited for at the end of the previous step, its LDS reads were consumed by the MFMAs
@@ -324,14 +348,20 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
         if constexpr (FULL64) dma_k(s_fetch, (s + 1) & 1);
 #endif
 #endif
-        const half8 q00 = *reinterpret_cast<const half8*>(qtile + f_rd), q01 = *reinterpret_cast<const half8*>(qtile + (f_rd ^ 64));
+        const unsigned char* qlo = (Q2 && kAlt) ? qalt : qtile;
+        const half8 q00 = *reinterpret_cast<const half8*>(qlo + f_rd), q01 = *reinterpret_cast<const half8*>(qlo + (f_rd ^ 64));
         const half8 q10 = *reinterpret_cast<const half8*>(qtile + 16 * kTapRow + f_rd);
         const half8 q11 = *reinterpret_cast<const half8*>(qtile + 16 * kTapRow + (f_rd ^ 64));
 #if DAAM_TAP_DMA && DAAM_TAP_EARLY_DMA
         if constexpr (FULL64) {
             // this wave's Q tile is free once its four operand reads have returned: the next step's rows are requested BEFORE the MFMAs
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            dma_q(s_fetch);
+            if constexpr (Q2) {
+                dma_q_hi(s_fetch);                                  // one step ahead, as before
+                dma_q_lo(min(s + 2, n_steps - 1), kAlt);            // two steps ahead, into the buffer just read
+            } else {
+                dma_q(s_fetch);
+            }
         }
 #endif
         floatx4 c0[5], c1[5];
@@ -407,7 +437,8 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
 #if DAAM_TAP_TOUCH
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // the DMAs have landed; the two touches (issued last) may still be in flight
 #else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs have landed; the next step's barrier publishes K
+            if constexpr (Q2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // all but the two newest (rows 0..15 of step s + 2) have landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs have landed; the next step's barrier publishes K
 #endif
         }
 #else
@@ -419,6 +450,7 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
     if constexpr (FULL64) {
         dma_k(0, 0);
         dma_q(0);
+        if constexpr (Q2) dma_q_lo(min(1, n_steps - 1), true);   // rows 0..15 of step 1 -> second buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         issue_k(0);
@@ -434,7 +466,16 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
     commit_k(0);
     commit_q();
 #endif
-    for (int s = 0; s < n_steps; ++s) step(s);
+    if constexpr (Q2) {
+        int s = 0;
+        for (; s + 1 < n_steps; s += 2) {
+            step(s, std::false_type{});
+            step(s + 1, std::true_type{});
+        }
+        if (s < n_steps) step(s, std::false_type{});
+    } else {
+        for (int s = 0; s < n_steps; ++s) step(s, std::false_type{});
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of the last (redundant) fetches is in flight any more
     __syncthreads();                                          // all K reads done before the staging tile reuses the space
 
@@ -467,23 +508,30 @@ bool tap_d64_supported(int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t
     return ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
 }
 
-template <typename IN, typename ACC_T, bool FAST, bool FULL64, int WAVES = 4>
+template <typename IN, typename ACC_T, bool FAST, bool FULL64, int WAVES = 4, bool Q2 = false>
 static hipError_t launch_d64_k(const TapLaunch& L, hipStream_t stream, int grid, size_t lds)
 {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_d64_kernel<IN, ACC_T, FAST, FULL64, WAVES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_d64_kernel<IN, ACC_T, FAST, FULL64, WAVES, Q2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((tap_d64_kernel<IN, ACC_T, FAST, FULL64, WAVES>), dim3(grid), dim3(64 * WAVES), lds, stream, L);
+    hipLaunchKernelGGL((tap_d64_kernel<IN, ACC_T, FAST, FULL64, WAVES, Q2>), dim3(grid), dim3(64 * WAVES), lds, stream, L);
     return hipGetLastError();
 }
 
 template <typename IN, typename ACC_T, bool FAST>
-static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out, bool full64, bool waves8)
+static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out, bool full64, int waves8)
 {
     constexpr bool kW8Build = (DAAM_TAP_W8 != 0) & (DAAM_TAP_DMA != 0);
     if constexpr (kW8Build) {                                 // round 5: every dtype pair (bf16 Q / K and f32 sums fit 128 VGPRs at 119-128, no spills)
+        if constexpr (sizeof(ACC_T) == 2) {                     // (f32 sums: the loop unrolled by two spills at 128 VGPRs -- they keep one step ahead)
+            if (waves8 == 2 && full64) {                        // Q2: rows 0..15 of the Q tiles two steps ahead
+                const size_t lds8 = tap_d64_lds_bytes<ACC_T, 8, true>();
+                *lds_out = lds8;
+                return launch_d64_k<IN, ACC_T, FAST, true, 8, true>(L, stream, grid, lds8);
+            }
+        }
         if (waves8 && full64) {
             const size_t lds8 = tap_d64_lds_bytes<ACC_T, 8>();
             *lds_out = lds8;
@@ -512,15 +560,15 @@ hipError_t launch_tap_d64(const TapLaunch& L, int in_dtype, int acc_dtype, int f
     size_t lds = 0;
     hipError_t e;
     if (in_dtype == 2) {                                       // bf16 pipeline: one softmax flavour
-        if (acc_dtype == 2) e = launch_d64<InBF16, bf16_t, true>(L, stream, grid, &lds, full64 != 0, waves8 != 0);
-        else if (acc_dtype == 1) e = launch_d64<InBF16, float, true>(L, stream, grid, &lds, full64 != 0, waves8 != 0);
+        if (acc_dtype == 2) e = launch_d64<InBF16, bf16_t, true>(L, stream, grid, &lds, full64 != 0, waves8);
+        else if (acc_dtype == 1) e = launch_d64<InBF16, float, true>(L, stream, grid, &lds, full64 != 0, waves8);
         else return hipErrorInvalidValue;
     } else if (acc_dtype != 0 && acc_dtype != 1) {
         return hipErrorInvalidValue;
     } else if (fast_exp) {
-        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, true>(L, stream, grid, &lds, full64 != 0, waves8 != 0) : launch_d64<InF16, float, true>(L, stream, grid, &lds, full64 != 0, waves8 != 0);
+        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, true>(L, stream, grid, &lds, full64 != 0, waves8) : launch_d64<InF16, float, true>(L, stream, grid, &lds, full64 != 0, waves8);
     } else {
-        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, false>(L, stream, grid, &lds, full64 != 0, waves8 != 0) : launch_d64<InF16, float, false>(L, stream, grid, &lds, full64 != 0, waves8 != 0);
+        e = acc_dtype == 0 ? launch_d64<InF16, _Float16, false>(L, stream, grid, &lds, full64 != 0, waves8) : launch_d64<InF16, float, false>(L, stream, grid, &lds, full64 != 0, waves8);
     }
     *lds_out = (int)lds;
     return e;

@@ -79,15 +79,18 @@ __device__ __forceinline__ int slab_logical_block(const TapLaunch& L)
     return -1;
 }
 
-template <int D, typename ACC_T, bool FAST_EXP>
+// TP = pixels per workgroup: 32, or -- head_dim 40 only -- 16: the half-size workgroups that take the last pixels of the head_dim-40
+// layers at the end of the launch (one 16-pixel group per wave, half the step chain's work: the chip drains more evenly)
+template <int D, int TP, typename ACC_T, bool FAST_EXP>
 __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& L, const TapLayer& lay, int wg)
 {
     constexpr int PPH = D / 8;                                // 16-byte pieces per head row: 5 / 10 / 20
     constexpr int NH = kSlabSlots / PPH;                      // heads per slab: 8 / 4 / 2
     constexpr int NKS = (PPH + 3) / 4;                        // k-steps of 32 elements: 2 / 3 / 5 (the last one partial for 40 and 80)
-    constexpr int G = NH == 8 ? 2 : 1;                        // 16-pixel groups per wave
-    constexpr int ITEMS = NH * (2 / G);                       // waves with arithmetic to do: 8 / 8 / 4
+    constexpr int G = NH == 8 ? TP / 16 : 1;                  // 16-pixel groups per wave
+    constexpr int ITEMS = NH * (TP / 16 / G);                 // waves with arithmetic to do: 8 / 8 / 4
     constexpr int TW = 16 * G;                                // pixels per wave
+    static_assert(TP == kSlabPx || (TP == 16 && D == 40), "half-size tiles: head_dim 40 only");
     constexpr int VEC = AccVec<ACC_T>::kPerVec;
     constexpr int PPRW = TW / VEC;                            // 16-byte pieces per staged row of a wave
     static_assert(NH * PPH == kSlabSlots && (PPH % 4 == 0 || NKS * 4 - PPH < 4), "slab geometry");
@@ -102,7 +105,7 @@ __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& 
     const int n_steps = lay.n_steps;
     const int rel = wg - lay.wg_begin;
     const int slab = rel / lay.tiles_per_head;                // tiles_per_head = tiles per slab here
-    const int p0 = (rel - slab * lay.tiles_per_head) * kSlabPx;
+    const int p0 = lay.px_begin + (rel - slab * lay.tiles_per_head) * TP;
     const int kh0 = slab * NH;                                // first kept head of the slab
     const int bh = lay.bh_first + kh0;
     const int b = bh / lay.heads, hd0 = bh - b * lay.heads;
@@ -117,7 +120,7 @@ __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& 
     if (!lay.fresh && active) {
         for (int piece = lane; piece < kTok * PPRW; piece += 64) {
             const int row = piece / PPRW, col = (piece - row * PPRW) * VEC;
-            if (px0 + col < lay.hw)
+            if (px0 + col < lay.px_end)
                 *reinterpret_cast<float4v*>(stage + row * TW + col) = *as_global<float4v>(acc + (size_t)row * lay.hw + px0 + col);
         }
 #pragma unroll
@@ -174,7 +177,7 @@ __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& 
     const unsigned k_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(k_off * 2));
     const unsigned q_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(q_off * 2));
     const unsigned k16 = (unsigned)__builtin_amdgcn_readfirstlane(16 * (int)lay.k_st * 2);                        // bytes per 16 token rows
-    const unsigned q16 = (unsigned)__builtin_amdgcn_readfirstlane(lay.hw - p0 >= kSlabPx ? 16 * (int)lay.q_sp * 2 : 0);   // ... 16 pixel rows
+    const unsigned q16 = (unsigned)__builtin_amdgcn_readfirstlane(lay.px_end - p0 >= kSlabPx ? 16 * (int)lay.q_sp * 2 : 0);   // ... 16 pixel rows
     const unsigned kB_s = k_base + (unsigned)(wave >> 1) * k16;
     const unsigned xq_s = q_base + (unsigned)(wave >> 1) * q16;
     const int kB_lds = (wx + 10 * (wave >> 1)) * 1024;
@@ -195,8 +198,9 @@ __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& 
     auto dma_q = [&](int s) {                                 // two instructions (waves 0..3: three)
         const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + kSlabQOff + wave * 1024), 16, qdA, q_base, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + kSlabQOff + (wave + 10) * 1024), 16, qdA, q_base + q16, 0, 0);
-        if (wave < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + xq_lds), 16, xd, xq_s, 0, 0);
+        if constexpr (TP == kSlabPx)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + kSlabQOff + (wave + 10) * 1024), 16, qdA, q_base + q16, 0, 0);
+        if (wave < TP / 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + xq_lds), 16, xd, xq_s, 0, 0);   // 16-pixel tiles: instructions 8, 9 only
     };
 
     // ---- operand reads: lane (j, h) of k-step ks takes piece 4 ks + h of its head from row j of a 16-row tile; the same offset
@@ -289,7 +293,7 @@ __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& 
         }
         for (int piece = lane; piece < kTok * PPRW; piece += 64) {
             const int row = piece / PPRW, col = (piece - row * PPRW) * VEC;
-            if (px0 + col < lay.hw)
+            if (px0 + col < lay.px_end)
                 *as_global_rw<float4v>(acc + (size_t)row * lay.hw + px0 + col) = *reinterpret_cast<const float4v*>(stage + row * TW + col);
         }
     }
@@ -308,9 +312,12 @@ __global__ __launch_bounds__(64 * kSlabWaves, 4) void tap_slab_kernel(const TapL
     const DAAM_GLOBAL TapLayer* gl = as_global<TapLayer>(L.layers);
     load_layer(gl + mfma_find_layer(gl, L.n_layers, wg), &lay);
     switch (lay.head_dim) {                                   // wave-uniform
-    case 40: slab_body<40, ACC_T, FAST_EXP>(smem, L, lay, wg); break;
-    case 80: slab_body<80, ACC_T, FAST_EXP>(smem, L, lay, wg); break;
-    default: slab_body<160, ACC_T, FAST_EXP>(smem, L, lay, wg); break;
+    case 40:
+        if (lay.tile_px == 16) slab_body<40, 16, ACC_T, FAST_EXP>(smem, L, lay, wg);
+        else slab_body<40, kSlabPx, ACC_T, FAST_EXP>(smem, L, lay, wg);
+        break;
+    case 80: slab_body<80, kSlabPx, ACC_T, FAST_EXP>(smem, L, lay, wg); break;
+    default: slab_body<160, kSlabPx, ACC_T, FAST_EXP>(smem, L, lay, wg); break;
     }
 }
 

@@ -41,6 +41,9 @@ struct TapLayer {
     int32_t fresh;          // 1: running sums are known to be zero (first tap since reset): skip the read
     int64_t q_sb, q_sh, q_sp;
     int64_t k_sb, k_sh, k_st;
+    // tap_slab_kernel: the entry covers the pixels [px_begin, px_end) of the layer in tiles of tile_px (a layer may have two entries: its
+    // last pixels in half-size tiles at the end of the launch); every other kernel has [0, hw) and its own tile size
+    int32_t px_begin, px_end, tile_px;
 };
 
 struct TapPtr {

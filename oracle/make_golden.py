@@ -34,7 +34,27 @@ import torch
 
 from oracle import fake_diffusers as fd
 
-OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+# DAAM_GOLDEN_OUT: write somewhere else (tools/golden_host_check.py regenerates into a scratch directory and compares)
+OUT_DIR = os.environ.get('DAAM_GOLDEN_OUT') or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+def host_info() -> dict:
+    """The host a fixture was generated on.  The fp32 cases do not depend on it (bit for bit on every host tried); the literal fp16 /
+    bf16 cases do in their last bit: another CPU sums the fp16 GEMM in another order, which flips the rounding of an fp16 logit in
+    0.01-0.2 % of the elements (tests/golden/PROVENANCE.json has the comparison between hosts)."""
+    cpu = 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                cpu = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        isa = torch.backends.cpu.get_cpu_capability()
+    except Exception:                                            # noqa: BLE001
+        isa = 'unknown'
+    return dict(cpu=cpu, cpu_capability=isa, torch=torch.__version__, threads=torch.get_num_threads())
 
 LONG_PROMPT = ' '.join(f'w{i}' for i in range(75))     # 75 tokens -> 77 rows
 
@@ -220,6 +240,7 @@ def run_case(name, spec, daam):
     meta['reference'] = 'castorini/daam v0.2.0, executed unmodified via oracle/fake_diffusers.py'
     meta['fp16_note'] = 'fp16 accumulators cast to fp32 before compute_global_heat_map (CUDA autocast emulation)'
     meta['torch'] = torch.__version__
+    meta['host'] = host_info()
     out['meta'] = np.asarray(json.dumps(meta))
     path = os.path.join(OUT_DIR, f'{name}.npz')
     np.savez_compressed(path, **out)

@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ['--steps', '3', '--warmup', '1', '--no-baselines', '--no-integrated', '--no-other-configs']
 
 
-def _bench(*extra, timeout=600):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+def _bench(*extra, timeout=600, **env_extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **env_extra)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *COMMON, *extra], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -36,12 +36,35 @@ def test_bench_two_ranks_one_device():
     assert one['config']['collective_world_size'] == 1 and one['config']['collective_library'] is None
     assert two['config']['collective_world_size'] == 2 and two['config']['collective_library'].startswith('gloo')
     # the single-rank line measured its HBM traffic in the run (two children under rocprofv3 --pmc)
-    assert one['roofline']['traffic_measured_in_run'] is True, one['roofline'].get('traffic_in_run_note')
-    assert 0.9 <= one['roofline']['traffic_over_algorithmic'] <= 1.3, one['roofline']
+    import shutil
+    if shutil.which('rocprofv3') is None or 'traffic_in_run_note' in one['roofline']:
+        # no profiler / no PMC access on this box: bench.py degrades to the committed counters and says why -- not a failure of the bench
+        assert one['roofline']['traffic_measured_in_run'] is False and one['roofline'].get('traffic_in_run_note'), one['roofline']
+    else:
+        # (a box without the profiler / without PMC access: bench.py degrades to the committed counters and says why -- not a failure)
+    import shutil
+    if shutil.which('rocprofv3') is None or one['roofline'].get('traffic_in_run_note'):
+        assert one['roofline']['traffic_measured_in_run'] is False and one['roofline'].get('traffic_in_run_note'), one['roofline']
+    else:
+        assert one['roofline']['traffic_measured_in_run'] is True, one['roofline']
+        assert 0.9 <= one['roofline']['traffic_over_algorithmic'] <= 1.3, one['roofline']
     # two ranks share one GPU: the aggregate rate is about the single-rank rate (never the 2x of two devices), minus the
     # host-staged gather of 2 x 3 maps inside the timed region
-    assert 0.1 * one["value"] <= two["value"] <= 1.5 * one["value"], (one['value'], two['value'])
+    # (lower bound: the two ranks' 3-generation regions are 7 ms each next to a gather staged through the host and a gloo barrier,
+    # measured 0.35-0.9x; below 0.3x something serialises that should not)
+    assert 0.3 * one["value"] <= two["value"] <= 1.5 * one["value"], (one['value'], two['value'])
     assert two['roofline']['launches_per_generation'] == 1 and two['roofline']['frac'] > 0.1
+    # the single-rank line carries the sustained-state figure next to the (short) timed region; multi-rank lines do not
+    assert one['sustained']['seconds'] >= 2.0 and one['sustained_maps_per_s'] > 0 and one['sustained_tap_ms'] > 0, one.get('sustained')
+    assert 'sustained' not in two
+    assert two['config']['rank_cpu_affinity'] is None or 'cores' in two['config']['rank_cpu_affinity']
+
+
+def test_bench_two_ranks_without_the_launcher_module():
+    """``BENCH_NO_TORCHRUN=1``: the ranks are started by hand (what bench.py does when ``torch.distributed.run`` cannot be imported):
+    same env:// rendezvous, same line."""
+    two = _bench('--gpus', '2', '--dist-backend', 'gloo', '--shared-device', BENCH_NO_TORCHRUN='1')
+    assert two['n_gpus'] == 2 and two['config']['collective_world_size'] == 2 and two['value'] > 0
 
 
 def test_bench_eight_ranks_one_device():

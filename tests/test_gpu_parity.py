@@ -719,6 +719,60 @@ def test_full_size_layer_properties(heads, side, d):
     eng.close()
 
 
+@pytest.mark.parametrize('side', [24, 48])
+@pytest.mark.parametrize('mode', ['f16_exact', 'bf16_exact', 'f16_f32acc'])
+def test_eight_wave_partial_tiles_50_deferred_steps_vs_oracle(side, mode, monkeypatch):
+    """The eight-wave head_dim-64 form (256-pixel tiles; round 5: for bf16 / f32 sums as well) on layers whose last tile is PARTIAL --
+    hw = 576 (SD-2.x at 768 px: 2.25 tiles) and 2304 (9 tiles) -- through a 50-step deferred launch, against the numpy oracle; and
+    bit-identical to the form that requests half of every Q tile two steps ahead (DAAM_TAP_Q2=1, opt-in) and to the four-wave form
+    (DAAM_TAP_W8=0).  Reference: daam/trace.py:233,240 (unravel), heatmap.py:153-156 (the running sum)."""
+    import ctypes
+    from daam_amd import _native as nat
+    from daam_amd import engine as E
+    heads, d, steps, hw = 2, 64, 50, side * side
+    rng = np.random.default_rng(side * 31 + len(mode))
+    np_dt = ho.BF16 if mode.startswith('bf16') else np.float16
+    acc_np = np_dt if mode.endswith('_exact') else np.float32
+    scale = d ** -0.5
+    qs, ks = zip(*[_qk(rng, 2, heads, hw, d, np_dt) for _ in range(steps)])
+    want = _oracle_steps(qs, ks, heads, scale, np_dt, acc_np).astype(np.float64)
+    got = {}
+    for tag, env in (('default', {}), ('two_steps_ahead', dict(DAAM_TAP_Q2='1')), ('four_waves', dict(DAAM_TAP_W8='0'))):
+        E.release_parked_contexts()                          # the switches are read when a native context is created
+        for var in ('DAAM_TAP_Q2', 'DAAM_TAP_W8'):
+            monkeypatch.delenv(var, raising=False)
+        for var, val in env.items():
+            monkeypatch.setenv(var, val)
+        eng = _engine(accumulate='exact' if mode.endswith('_exact') else 'float32', defer_steps=64)
+        for q, k in zip(qs, ks):
+            eng.tap_qk(0, _dev(q, np_dt), _dev(k, np_dt), heads, scale, factor=1)
+        got[tag] = torch.stack([v.float() for _, v in eng.items()]).cpu()
+        assert eng.last_flush()['max_steps'] == steps
+        grid, block, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        nat.check(eng.lib.daam_last_launch(eng.ctx, 0, ctypes.byref(grid), ctypes.byref(block), ctypes.byref(lds)))
+        assert block.value == (256 if tag == 'four_waves' else 512), (tag, block.value)
+        if tag != 'four_waves':
+            assert grid.value >= heads * -(-hw // 256)       # 256-pixel tiles: 3 / 9 per head (the grid is rounded up to 8 XCDs)
+            two_ahead = tag == 'two_steps_ahead' and not mode.endswith('_f32acc')
+            assert (lds.value >= 69 * 1024) == (two_ahead or mode.endswith('_f32acc')), (tag, lds.value)
+        eng.close()
+    E.release_parked_contexts()
+    assert torch.equal(got['default'], got['two_steps_ahead']) and torch.equal(got['default'], got['four_waves'])
+    g = got['default'].numpy().astype(np.float64)
+    assert g.shape == want.shape
+    # tolerance of the 50-step full-size tests (tests/test_gpu_integration.py): the implementations round at the same points but sum
+    # q.k in another order, which flips the rounding of a logit now and then; an fp16 / bf16 running sum then differs by an ulp of
+    # ITS magnitude at most a few times over 50 steps
+    ulp = 2.0 ** -8 if mode.startswith('bf16') else 2.0 ** -11
+    if mode.endswith('_exact'):
+        tol = 2.0 ** -6 * np.abs(want) + 2 * ulp * max(1.0, want.max()) if not mode.startswith('bf16') else 2.0 ** -4 * np.abs(want) + 2 * ulp * max(1.0, want.max())
+    else:
+        tol = steps * ulp
+    bad = np.abs(g - want) > tol
+    assert not bad.any(), f'{mode} side {side}: {bad.sum()} elements beyond tolerance, max-abs {np.abs(g - want).max()}'
+    np.testing.assert_allclose(g.sum(1), steps, atol=steps * 77 * ulp)      # every step's probabilities sum to one over the tokens
+
+
 # ---------------------------------------------------------------------------------------------
 # property tests (hypothesis): random layer shapes / step counts / launch structures
 # ---------------------------------------------------------------------------------------------

@@ -15,10 +15,14 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _engine(monkeypatch, slab, n_layers, accumulate, defer, chunked=None):
+def _engine(monkeypatch, slab, n_layers, accumulate, defer, chunked=None, tail=None):
     from daam_amd import engine as E
     E.release_parked_contexts()                       # the switches are read when a native context is created
     monkeypatch.setenv('DAAM_TAP_SLAB', '1' if slab else '0')
+    if tail is None:
+        monkeypatch.delenv('DAAM_SLAB_TAIL', raising=False)
+    else:
+        monkeypatch.setenv('DAAM_SLAB_TAIL', str(tail))
     if chunked is None:
         monkeypatch.delenv('DAAM_TAP_CHUNKED', raising=False)
     else:
@@ -71,15 +75,18 @@ SLAB_CASES = [
 ]
 
 
+@pytest.mark.parametrize('tail', [None, 0, 100, 60])
 @pytest.mark.parametrize('accumulate', ['exact', 'float32'])
-def test_slab_layers_bit_identical_to_chunked_kernel(monkeypatch, accumulate):
+def test_slab_layers_bit_identical_to_chunked_kernel(monkeypatch, accumulate, tail):
+    """``tail`` = DAAM_SLAB_TAIL: the share of a head_dim-40 layer's pixels taken by half-size (16-pixel) workgroups at the end of the
+    launch (default 25 %; 0 = none, 100 = all of them): the same sums bit for bit."""
     steps = 5
     sets = _inputs(SLAB_CASES, steps, seed=11)
     ref_eng = _engine(monkeypatch, False, len(SLAB_CASES), accumulate, 8)
     ref, rflush, rlaunch = _run(ref_eng, SLAB_CASES, sets, rounds=2)
     ref_eng.close()
     assert rlaunch['block'] == 256, rlaunch                          # the chunked kernel
-    got_eng = _engine(monkeypatch, True, len(SLAB_CASES), accumulate, 8)
+    got_eng = _engine(monkeypatch, True, len(SLAB_CASES), accumulate, 8, tail=tail)
     got, flush, launch = _run(got_eng, SLAB_CASES, sets, rounds=2)
     got_eng.close()
     assert flush['kernels'] == 1 and flush['side_streams'] == 0 and flush['max_steps'] == steps, flush
@@ -107,8 +114,9 @@ def test_slab_sd15_launch_one_kernel_bit_identical_to_specialised_kernels(monkey
     got_eng.close()
     assert flush['kernels'] == 1 and flush['side_streams'] == 0 and flush['max_steps'] == 50, flush
     assert launch['block'] == 512, launch
-    # 640 + 320 + 168 workgroups, an eighth of each segment per XCD
-    assert launch['grid'] == 8 * (21 + 80 + 40), launch
+    # segments: 168 head_dim-160 workgroups, 5 x 96 of head_dim 40 (32-pixel tiles: the first three quarters of each layer), 320 of head_dim
+    # 80, 5 x 64 half-size ones (16-pixel tiles: the last quarter of the head_dim-40 layers); an eighth of each segment per XCD
+    assert launch['grid'] == 8 * (21 + 60 + 40 + 40), launch
     assert len(got) == 128
     for key in ref:
         assert torch.equal(got[key], ref[key]), key

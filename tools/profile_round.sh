@@ -8,7 +8,7 @@ TAG=${1:-r03}; WL=${2:-sdxl1024}; DS=${3:-50}; DEFER=${4:-$DS}; NSTAT=${5:-30}; 
 KEY=$WL:defer$DEFER:exact
 R=$(pwd); O=$R/gpurun_out/prof_${TAG}_$WL
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-ARGS="--no-baselines --no-integrated --no-other-configs --workload $WL --denoise-steps $DS"
+ARGS="--no-baselines --no-integrated --no-other-configs --no-pmc --no-sustained --workload $WL --denoise-steps $DS"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py $ARGS --steps $NSTAT --warmup 2 > $O/stats.log 2>&1
 PM="python $R/bench.py $ARGS --steps $NPMC --warmup 2"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- $PM > $O/pmc_sq.log 2>&1

@@ -1,9 +1,9 @@
 #!/bin/bash
 # The round's evidence in one gpurun call: the -m gpu suite, kernel stats + PMC passes of the three single-GPU configurations
 # (tools/profile_round.sh), the bench lines (default form and the driver's form) and the power / clock traces.
-#   gpurun --timeout 2400 -- 'bash tools/round_evidence.sh r04'        -> gpurun_out/evidence_<tag>/ + gpurun_out/profiles_<tag>/
+#   gpurun --timeout 2400 -- 'bash tools/round_evidence.sh r05'        -> gpurun_out/evidence_<tag>/ + gpurun_out/profiles_<tag>/
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "$(dirname "$0")/.."
 out=gpurun_out/evidence_$TAG
 mkdir -p "$out"

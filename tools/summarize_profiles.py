@@ -26,7 +26,7 @@ def find(d, suffix):
 def short(name):
     if 'daam' not in name:
         return None
-    for k in ('tap_d64_kernel', 'tap_chunk_kernel', 'tap_wide_kernel', 'tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'attend_kernel', 'finalize_up32_pipe_kernel',
+    for k in ('tap_d64_kernel', 'tap_slab_kernel', 'tap_chunk_kernel', 'tap_wide_kernel', 'tap_mfma_kernel', 'tap_generic_kernel', 'tap_probs_kernel', 'attend_kernel', 'finalize_up32_pipe_kernel',
               'finalize_up32_same_kernel', 'finalize_up32_mfma_kernel', 'finalize_down2_kernel',
               'finalize_up_kernel', 'finalize_same_kernel', 'finalize_kernel', 'normalize_kernel', 'word_'):
         if k in name:
@@ -72,7 +72,7 @@ def main():
         tpath = os.path.join(a.out, 'hbm_traffic.json')
         traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
         rec = {}
-        for kern, field in (('tap_d64_kernel', 'tap'), ('tap_chunk_kernel', 'tap'), ('tap_mfma_kernel', 'tap'), ('finalize_up32_pipe_kernel', 'finalize_pipe'),
+        for kern, field in (('tap_d64_kernel', 'tap'), ('tap_slab_kernel', 'tap'), ('tap_chunk_kernel', 'tap'), ('tap_mfma_kernel', 'tap'), ('finalize_up32_pipe_kernel', 'finalize_pipe'),
                             ('finalize_up32_same_kernel', 'finalize_pair'), ('finalize_up32_mfma_kernel', 'finalize_up'),
                             ('finalize_same_kernel', 'finalize_same')):
             cs = pmc.get(kern, {})
@@ -109,7 +109,7 @@ def main():
         def upper_median(v):
             v = sorted(v)
             return statistics.median(v[len(v) // 2:])
-        tap_names = [k for k in ('tap_d64_kernel', 'tap_chunk_kernel', 'tap_wide_kernel', 'tap_mfma_kernel') if k in pmc and 'SQ_ACTIVE_INST_VALU' in pmc[k]]
+        tap_names = [k for k in ('tap_d64_kernel', 'tap_slab_kernel', 'tap_chunk_kernel', 'tap_wide_kernel', 'tap_mfma_kernel') if k in pmc and 'SQ_ACTIVE_INST_VALU' in pmc[k]]
         if tap_names:
             w['tap_kernels_per_launch'] = len(tap_names)          # bench.py drops the tap counters when the launch structure differs
             # a flush may run several tap kernels side by side (SD-v1.5): their work adds up on the same SIMDs
