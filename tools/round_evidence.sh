@@ -30,8 +30,8 @@ say "bench driver form: $(python -c "import json;r=json.loads([l for l in open('
 [ "${SKIP_POWER:-0}" = 1 ] || for pool in 0 12; do
   O=$out/power_pool$pool; mkdir -p $O
   sample() { rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | sed -E 's/^GPU\[0\][[:space:]]*:[[:space:]]*//' | tr '\n' ';'; echo; }
-  echo "# python bench.py --no-baselines --no-integrated --no-other-configs --no-pmc --steps 3000 --warmup 10 --pool $pool   (pool 0 = one distinct step set per denoising step)" > $O/power_sclk.txt
-  python bench.py --no-baselines --no-integrated --no-other-configs --no-pmc --steps 3000 --warmup 10 --pool $pool > $O/bench.json 2> /dev/null &
+  echo "# python bench.py --no-baselines --no-integrated --no-other-configs --no-pmc --no-sustained --steps 3000 --warmup 10 --pool $pool   (pool 0 = one distinct step set per denoising step)" > $O/power_sclk.txt
+  python bench.py --no-baselines --no-integrated --no-other-configs --no-pmc --no-sustained --steps 3000 --warmup 10 --pool $pool > $O/bench.json 2> /dev/null &
   BP=$!
   while kill -0 $BP 2>/dev/null; do echo "$(date +%s.%N) $(sample)" >> $O/power_sclk.txt; sleep 0.3; done
   python -c "
