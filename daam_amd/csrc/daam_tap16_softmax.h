@@ -76,18 +76,34 @@ __device__ __forceinline__ bool softmax_sum_out_of_range(float tot)
 template <bool PREMASKED = false>
 __device__ __forceinline__ void softmax20_probs_bf16(const floatx4 (&c)[5], float scale, int h, float2v (&p)[kSlots16 / 2])
 {
+    // scale a power of two (head_dim 64: 1/8): the multiply commutes with the bf16 rounding (bf16(c) * 2^k == bf16(c * 2^k) unless the
+    // result is a bf16 subnormal), so the logits stay unscaled and the scale is folded into L -- as in the fp16 path; 10 packed
+    // multiplies fewer per 16 pixels (round 5).  The conversion is the COMPILER's v_cvt_pk_bf16_f32 there (not the asm helper): it is the
+    // first VALU read of the MFMA results, and only instructions the compiler can see get their MFMA -> VALU wait states padded.
+    const bool pow2 = (__float_as_uint(scale) & 0x007fffffu) == 0;         // wave-uniform
     float2v x[kSlots16 / 2];
+    if (pow2) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int mt = 0; mt < 5; ++mt) {
-        x[2 * mt] = round_bf16_pair(float2v{c[mt][0], c[mt][1]} * scale);
-        x[2 * mt + 1] = round_bf16_pair(float2v{c[mt][2], c[mt][3]} * scale);
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned r = __builtin_bit_cast(unsigned, __builtin_convertvector(float2v{c[mt][2 * u], c[mt][2 * u + 1]}, bf16x2));
+                x[2 * mt + u] = float2v{__uint_as_float(r << 16), __uint_as_float(r & 0xffff0000u)};
+            }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+            x[2 * mt] = round_bf16_pair(float2v{c[mt][0], c[mt][1]} * scale);
+            x[2 * mt + 1] = round_bf16_pair(float2v{c[mt][2], c[mt][3]} * scale);
+        }
     }
     if (!PREMASKED && h == 3) {                                          // tokens 77, 78, 79 (PREMASKED: -inf from the MFMA chain start)
         const float ninf = -__builtin_inff();
         x[8][1] = ninf;
         x[9] = float2v{ninf, ninf};
     }
-    const float L = 1.44269502162933349609375f;
+    const float L = 1.44269502162933349609375f * (pow2 ? scale : 1.0f);   // exact: power-of-two factor
     float2v ev[kSlots16 / 2];
     auto exps = [&](float nmL) -> float {
         float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};

@@ -36,6 +36,13 @@
 // Debug aid (tools/exp/slab_timeline.py; build with -DDAAM_SLAB_TIMING): per-workgroup stamps -- 100 MHz reference counter at the start, at
 // the first step, after the last step and at the end; shader cycles wave 0 spent waiting at the head of the steps (DMA wait + barrier) and
 // in the whole loop; head_dim; HW_ID.
+// cache policy of the Q fetches (every Q line is read exactly once per launch, by one workgroup): 2 = non-temporal (default), 0 = the default
+// policy (A/B: -DDAAM_SLAB_Q_AUX=0).  SD-v1.5, alternating three times on one box: 2517 / 2517 / 2515 -> 2583 / 2589 / 2579 maps/s, tap 0.351 ->
+// 0.342 ms with nt (the once-read Q lines no longer push the K slabs, which every tile of a layer re-reads, out of the L2s).  The same switch
+// on the head_dim-64 kernel (-DDAAM_TAP_Q_AUX=2) is neutral on the headline (its K tiles are 5x smaller per byte of Q).
+#ifndef DAAM_SLAB_Q_AUX
+#define DAAM_SLAB_Q_AUX 2
+#endif
 #ifdef DAAM_SLAB_TIMING
 __device__ unsigned long long daam_slab_dbg[4096][8];
 #define DAAM_ST(i, v) do { if (threadIdx.x == 0 && wg < 4096) daam_slab_dbg[wg][i] = (v); } while (0)
@@ -197,10 +204,10 @@ __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& 
     };
     auto dma_q = [&](int s) {                                 // two instructions (waves 0..3: three)
         const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + kSlabQOff + wave * 1024), 16, qdA, q_base, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + kSlabQOff + wave * 1024), 16, qdA, q_base, 0, DAAM_SLAB_Q_AUX);
         if constexpr (TP == kSlabPx)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + kSlabQOff + (wave + 10) * 1024), 16, qdA, q_base + q16, 0, 0);
-        if (wave < TP / 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + xq_lds), 16, xd, xq_s, 0, 0);   // 16-pixel tiles: instructions 8, 9 only
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + kSlabQOff + (wave + 10) * 1024), 16, qdA, q_base + q16, 0, DAAM_SLAB_Q_AUX);
+        if (wave < TP / 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + xq_lds), 16, xd, xq_s, 0, DAAM_SLAB_Q_AUX);   // 16-pixel tiles: instructions 8, 9 only
     };
 
     // ---- operand reads: lane (j, h) of k-step ks takes piece 4 ks + h of its head from row j of a 16-row tile; the same offset

@@ -452,6 +452,39 @@ def test_profile_history_times_every_launch_of_a_region():
     eng.close()
 
 
+def test_failed_announcement_still_launches_and_drops_the_recorded_calls():
+    """``flush(_before_launch=...)``: the recorded calls are in the library's hands when the announcement runs.  If it raises, the launch
+    that consumes them must still follow (the Python references to their Q / K are dropped right after: entries left pending would be
+    read from freed memory by the next launch) and the error must reach the caller.  (Advisor, round 4.)"""
+    import ctypes
+    from daam_amd import _native as nat
+    heads, hw, d = 2, 256, 64
+    g = torch.Generator(device=DEV).manual_seed(3)
+    q = torch.randn(2, hw, heads * d, generator=g, device=DEV, dtype=torch.float16)
+    k = torch.randn(2, 77, heads * d, generator=g, device=DEV, dtype=torch.float16)
+    ref = _engine(defer_steps=8)
+    ref.tap_qk(0, q, k, heads, d ** -0.5, factor=4)
+    ref.flush()
+    want = torch.stack([v.clone() for _, v in ref.items()])
+    ref.close()
+    eng = _engine(defer_steps=8)
+    eng.tap_qk(0, q, k, heads, d ** -0.5, factor=4)
+
+    def boom(stream):
+        raise RuntimeError('announcement failed')
+    with pytest.raises(RuntimeError, match='announcement failed'):
+        eng.flush(_before_launch=boom)
+    n_calls, max_steps = ctypes.c_int(-1), ctypes.c_int(-1)
+    nat.check(eng.lib.daam_tap_pending(eng.ctx, ctypes.byref(n_calls), ctypes.byref(max_steps)))
+    assert n_calls.value == 0 and eng.pending_taps == 0            # nothing left behind on either side
+    got = torch.stack([v.clone() for _, v in eng.items()])
+    assert torch.equal(got, want)                                    # the launch ran: the step is in the sums
+    eng.tap_qk(0, q, k, heads, d ** -0.5, factor=4)                # and the engine goes on working
+    eng.flush()
+    torch.cuda.synchronize()
+    eng.close()
+
+
 def test_views_survive_clear_and_next_generation():
     """``all_heat_maps`` hands out views of the live sums; like the reference's tensors (heatmap.py:170-172: clear() drops the
     dict, tensors handed out before live on) they must keep their values through clear() AND through the next

@@ -9,6 +9,7 @@ out=gpurun_out/evidence_$TAG
 mkdir -p "$out"
 T0=$SECONDS
 say() { echo "[evidence $((SECONDS - T0))s] $*"; }
+timeout 300 python __graft_entry__.py smoke > "$out/smoke.txt" 2>&1; say "smoke: $(tail -1 "$out/smoke.txt")"
 if [ "${SKIP_TESTS:-0}" != 1 ]; then
   timeout 900 python -m pytest tests -q -m gpu > "$out/gpu_tests.txt" 2>&1
   say "pytest -m gpu: $(tail -1 "$out/gpu_tests.txt")"
