@@ -446,8 +446,15 @@ def test_profile_history_times_every_launch_of_a_region():
     assert len(tap) == len(steps) and len(fin) == len(steps)
     assert all(0.0 < t < 50.0 for t in tap + fin), (tap, fin)
     assert history(0, 2) == tap[-2:]                                 # clipped to the newest launches, oldest first
+    # daam_profile_last_ms in ring mode reads the NEWEST ring slot (not a stale pair of an earlier mode-1 run)
+    last = ctypes.c_float()
+    nat.check(eng.lib.daam_profile_last_ms(eng.ctx, 0, ctypes.byref(last)))
+    assert last.value == tap[-1]
+    nat.check(eng.lib.daam_profile_last_ms(eng.ctx, 1, ctypes.byref(last)))
+    assert last.value == fin[-1]
     nat.check(eng.lib.daam_profile_enable(eng.ctx, 2))               # re-arming starts a new region
     assert history(0, 16) == []
+    assert eng.lib.daam_profile_last_ms(eng.ctx, 0, ctypes.byref(last)) != 0     # nothing launched in the new region yet: an error, not a stale time
     nat.check(eng.lib.daam_profile_enable(eng.ctx, 0))
     eng.close()
 
