@@ -708,6 +708,18 @@ def test_tap_chunk_data_path_model(head_dim, hw, p0):
     assert err < 2e-3 and finite
 
 
+def test_tap_slab_data_path_model():
+    """The index arithmetic of tap_slab_kernel (daam_tap_slab.hip: which instruction of which wave fetches which 16-byte piece into which
+    LDS slot -- per-lane offsets shared by instructions ten apart, scalar 16-row steps, the extra instructions of waves 0..3 / 4..7,
+    half-size tiles --, the swizzle, the operand reads of every wave role for head_dim 40 / 80 / 160, the zero piece behind the tail
+    k-step), modelled lane by lane on the host (tools/emulate_tap_slab.py), reproduces q . k for every (head of the slab, pixel, token) of
+    a workgroup of the LAST slab of the last batch (LDS poisoned before the fetches, NaN guard halves behind the tensors)."""
+    from tools import emulate_tap_slab as em
+    for case in em.CASES:
+        err, finite = em.check(verbose=False, **case)
+        assert err < 2e-3 and finite, case
+
+
 def test_committed_counters_are_tied_to_the_build_kernel_by_kernel():
     """profiles/r03_counters.json carries the machine-code fingerprint of every kernel of the build it was measured on; bench.py
     takes its numbers only while each of them is byte-identical in the library built from this tree (source files added since,
