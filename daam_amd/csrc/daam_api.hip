@@ -210,6 +210,7 @@ struct DaamCtx {
     std::vector<char> fin_tab_host;   // the bytes d_fin_tab holds (when fin_tab_valid)
     bool fin_tab_valid = false;
     hipStream_t fin_tab_stream = nullptr;   // the stream its upload and its readers were enqueued on
+    int tap_head_minor = 0;           // DAAM_TAP_HEAD_MINOR=1: head-minor workgroup numbering of the head_dim-64 deferred launches (A/B)
     int tap_q2 = 0;                   // DAAM_TAP_Q2=1: eight-wave head_dim-64 launches request half of every Q tile two steps ahead (round 5: built on the verdict's
                                       // advice, bit-identical, measured 1.3 % SLOWER on the headline -- 491-493 against 498 maps/s alternating on one box -- so it is opt-in)
     int no_w8 = 0;                    // debugging / A-B: DAAM_TAP_W8=0 (head_dim-64 launches on 4-wave workgroups of 128 pixels instead of 8-wave / 256)
@@ -436,6 +437,8 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->no_paired_finalize = npf && npf[0] == '1';
     const char* w8 = getenv("DAAM_TAP_W8");
     c->no_w8 = w8 && w8[0] == '0';
+    const char* hm = getenv("DAAM_TAP_HEAD_MINOR");
+    c->tap_head_minor = hm && hm[0] == '1';
     const char* q2 = getenv("DAAM_TAP_Q2");
     c->tap_q2 = q2 && q2[0] == '1';
     const char* nfc = getenv("DAAM_NO_FIN_CACHE");
@@ -1065,6 +1068,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         pr.L.wgs_per_xcd = (wg + 7) / 8;
         pr.L.n_seg = n_seg;
         for (int k = 0; k < 5; ++k) pr.L.seg_begin[k] = seg_begin[k];
+        pr.L.head_minor = ((kd == 65 || kd == 66) && c->tap_head_minor) ? 1 : 0;
         pr.max_d = max_d;
         pr.min_d = min_d;
         pr.all_round = all_round;

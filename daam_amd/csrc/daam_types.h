@@ -68,6 +68,9 @@ struct TapLaunch {
     // layers of one head_dim -- and every XCD takes an eighth of each segment
     int32_t n_seg;
     int32_t seg_begin[5];
+    // tap_d64_kernel: 1 = a layer's workgroups are numbered head-minor (tile, head) instead of (head, tile): the workgroups that run side by
+    // side on an XCD then read ADJACENT heads of the same pixel rows -- contiguous 128-byte pieces of the same DRAM pages (DAAM_TAP_HEAD_MINOR)
+    int32_t head_minor;
 };
 
 struct ProbsLaunch {        // daam_tap_probs
