@@ -18,7 +18,8 @@ fi
 [ "${SKIP_PROFILE:-0}" = 1 ] || for wl in sdxl1024 sd15 sdxl2048; do
   ds=50; [ $wl = sdxl2048 ] && ds=100
   dfr=$ds; [ $wl = sdxl2048 ] && dfr=64
-  timeout 500 bash tools/profile_round.sh $TAG $wl $ds $dfr 20 4 > "$out/profile_$wl.log" 2>&1
+  nstat=20; [ $wl = sd15 ] && nstat=100      # SD-v1.5: 100 generations = the length of the headline's 20 (a 9 ms region is over before the board leaves its idle clocks)
+  timeout 500 bash tools/profile_round.sh $TAG $wl $ds $dfr $nstat 4 > "$out/profile_$wl.log" 2>&1
   say "profile $wl: $(grep -c wrote "$out/profile_$wl.log") files"
 done
 # the bench lines read the counters measured minutes ago on this box (bench.py takes profiles/<tag>_counters.json when the kernels match)
