@@ -514,7 +514,7 @@ def measure_traffic(args, workload, denoise, launches_per_gen, timeout_s=200, sq
                     continue
                 for k in _TAP_KERNELS + _FIN_KERNELS:
                     if k in row['Kernel_Name']:
-                        vals.setdefault(k, {}).setdefault(row['Counter_Name'], []).append(float(row['Counter_Value']))
+                        vals.setdefault(k, {}).setdefault(row['Counter_Name'], []).append((int(row.get('Dispatch_Id') or 0), float(row['Counter_Value'])))
                         break
         except subprocess.TimeoutExpired:
             if optional:
@@ -524,11 +524,19 @@ def measure_traffic(args, workload, denoise, launches_per_gen, timeout_s=200, sq
         finally:
             shutil.rmtree(d, ignore_errors=True)
 
+    n_gen = 4                                                 # generations a --pmc-child runs (pmc_child)
+    # dispatch order; the FIRST generation's dispatches are dropped: its tap launch finds the sums known-zero and skips their read
+    # (a "fresh" launch), which would bias the mean launch's bytes low
+    for k in vals:
+        for cn in vals[k]:
+            v = [x for _, x in sorted(vals[k][cn])]
+            vals[k][cn] = v[len(v) // n_gen:] if len(v) >= n_gen else v
+
     def upper_median(v):
         v = sorted(v)
         return statistics.median(v[len(v) // 2:])
 
-    n_gen = 4                                                 # generations a --pmc-child runs (pmc_child)
+    n_gen -= 1
 
     def kernel_bytes(k):
         # mean over the kernel's dispatches: a generation of several tap launches has launches of different lengths (SDXL-2048: 64 + 36
@@ -548,7 +556,7 @@ def measure_traffic(args, workload, denoise, launches_per_gen, timeout_s=200, sq
                per_kernel=per, launches_per_generation=launches_per_gen,
                method='children of this run under rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); '
                       'bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 rule of MI355X_MICROARCH.md); mean over a kernel\'s dispatches '
-                      '(a generation of several tap launches: the mean launch, like bytes_per_launch)')
+                      'of generations 2-4 (a generation of several tap launches: the mean launch, like bytes_per_launch)')
 
     def per_simd(names, counter, scale=1.0):
         ks = [k for k in names if counter in vals.get(k, {})]
@@ -707,6 +715,7 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     w = torch.stack(warm[:max(2, min(gens, 256))])               # the region's stack of `gens` maps, too
     if comm:
         comm.all_gather(w)                                       # ... and one gather of the timed region's size (communicator, buffers)
+    warmup_effective = max(warmup, 1) + max(0, n_more)           # generations really run before the timed region
     del warm, w
     launches0 = eng.last_flush()['launches']
     from daam_amd import _native as nat
@@ -731,6 +740,7 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     elapsed = time.perf_counter() - t0
     launches_per_gen = (eng.last_flush()['launches'] - launches0) / gens     # what the engine really launched
     flush = eng.last_flush()
+    ran_tap, ran_fin = eng.last_kernels(0), eng.last_kernels(1)
 
     def history(which, want):
         import ctypes
@@ -781,7 +791,8 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     note(f'{name}: {world * gens / elapsed:.1f} maps/s; kernel measurements')
     acc_bytes = 2 if accumulate == 'exact' else 4
     out = dict(label=wl['label'], elapsed=elapsed, gens=gens, denoise_steps=denoise_steps, accumulate=accumulate,
-               value=world * gens / elapsed, ms_per_step=elapsed / gens * 1e3, keys=sum(h for _, h, _, _ in layers), sustained=sustained)
+               value=world * gens / elapsed, ms_per_step=elapsed / gens * 1e3, keys=sum(h for _, h, _, _ in layers), sustained=sustained,
+               warmup_effective=warmup_effective)
     # steps one tap launch covers: the step window, or fewer when the recorded Q / K reach the engine's
     # byte budget (a launch is then forced at the next step boundary)
     step_bytes = sum(q.numel() * q.element_size() + k.numel() * k.element_size() for q, k in sets[0])
@@ -842,11 +853,10 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
                      f'{flush["kernels"]}: {rec.get("tap_note", "not comparable")}')
         rec = {k: v for k, v in rec.items() if not k.startswith('tap_')}
     traffic = rec.get('tap_bytes_per_launch') if rec else None
-    tap_kernel = ('tap_d64_kernel (16x16x32 MFMA tiles, head_dim 64)' if wl['kind'] == 'sdxl'
-                  else 'tap_slab_kernel (head_dim 40 / 80 / 160: 640-byte slabs of adjacent heads, whole 128-byte lines of Q, every layer in ONE launch)'
-                  if flush['kernels'] == 1 and os.environ.get('DAAM_TAP_SLAB', '1') != '0'
-                  else 'tap_chunk_kernel (head_dim 40 / 80 / 160 in 64-element chunks, every layer in ONE launch)' if flush['kernels'] == 1
-                  else 'tap_d64_kernel (head_dim 40) + tap_wide_kernel<3|5> (head_dim 80 / 160), one flush = 3 kernels side by side')
+    # what the engine's last tap launch really launched (daam_last_kernels, ABI v6) -- not what the environment asked for
+    tap_kernel = ran_tap + {'tap_d64_kernel': ' (16x16x32 MFMA tiles, head_dim 64)',
+                            'tap_slab_kernel': ' (head_dim 40 / 80 / 160: 640-byte slabs of adjacent heads, every layer in ONE launch)',
+                            'tap_chunk_kernel': ' (any head_dim in 64-element chunks, every layer in ONE launch)'}.get(ran_tap, '')
     out['roofline'] = dict(bound='hbm', kernel=tap_kernel,
                            achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
                            traffic=traffic, traffic_measured_in_run=False,
@@ -901,11 +911,8 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
         fin_ms = sum(region_fin) / len(region_fin)             # the finalize calls of the timed region
     fin_bytes = acc_total + 77 * 64 * 64 * 4
     fin_gbs = fin_bytes / (fin_ms * 1e-3) / 1e9
-    fin_kernel = {'sdxl1024': 'finalize_up32_pipe_kernel (x2 class software-pipelined on the matrix cores; the same-size keys ride along)',
-                  'sdxl2048': 'finalize_down2 (128 -> 64) + finalize_same_kernel',
-                  'sd15': 'finalize_up32_pipe_kernel (x2 + same-size keys) + finalize_up_kernel<16>'}.get(name, 'the x2 / same-size class kernels of this sum dtype')
-    fin_kernel += ('; key tables cached on the device, output cleared by the upload kernel of the tap launch in front (daam_finalize_prepare, ABI v5): '
-                   'the timed call is the class kernel(s) only')
+    fin_kernel = ran_fin + ('; key tables cached on the device, output cleared by the upload kernel of the tap launch in front (daam_finalize_prepare): '
+                            'the timed call is the class kernel(s) only')
     fin_issue = dict(bound='matrix-pipe / issue', kernel=fin_kernel, clock=fin_clock, ms_per_launch=round(fin_ms, 4))
     if rec and fin_clock and rec.get('finalize_valu_busy_cycles_per_simd'):
         n_mfma = rec.get('finalize_mfma_per_simd', 0)
@@ -935,6 +942,97 @@ def run_workload(name, denoise_steps, gens, warmup, device, args, comm=None, ran
     del sets, calls
     torch.cuda.empty_cache()
     return out
+
+
+LINE_LIMIT = 4096             # bytes of the ONE stdout line (round 5's 25 KB line was dropped by the driver: BENCH_r05.parsed = null)
+FULL_RECORD = os.path.join('gpurun_out', 'bench_full.json')
+
+
+def _short(s, n=160):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + '...'
+
+
+def _pick(d, keys):
+    return {k: _short(d[k]) for k in keys if d and k in d and not isinstance(d[k], (dict, list))}
+
+
+def headline_line(full: dict) -> str:
+    """The ONE stdout line: the contract's fields + ``roofline`` + ``cpu_baseline`` + one scalar per extra leg, strict JSON,
+    < LINE_LIMIT bytes.  Everything else ``main`` measured (per-kernel counter tables, issue rooflines, the other configurations'
+    full records, prose on sources) is in the full record (``gpurun_out/bench_full.json``, copied to ``profiles/`` per round)."""
+    line = _pick(full, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'warmup_effective', 'ms_per_step', 'higher_is_better',
+                        'scaling', 'vs_baseline', 'dtype', 'data'))
+    line['config'] = _pick(full.get('config'), ('workload', 'accumulate', 'defer_steps', 'parallelism', 'generations_per_rank', 'baseline_config',
+                                                'collective', 'collective_world_size', 'collective_library'))
+    line['roofline'] = _pick(full.get('roofline'), ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'bytes_per_launch', 'ms_per_launch',
+                                                    'traffic', 'traffic_over_algorithmic', 'traffic_measured_in_run', 'steps_per_launch',
+                                                    'launches_per_generation', 'sustained_frac'))
+    line['roofline'].setdefault('traffic', None)
+    cpu = full.get('cpu_baseline')
+    line['cpu_baseline'] = _pick(cpu, ('value', 'unit', 'cores', 'kind', 'cpu', 'sample')) if cpu else None
+    # one scalar per extra measurement, most important first (dropped from the END if the line would not fit)
+    extras = []
+
+    def add(key, value):
+        if value is not None:
+            extras.append((key, value))
+    rf = full.get('roofline_finalize') or {}
+    add('finalize_ms', rf.get('ms_per_launch'))
+    add('finalize_frac', rf.get('frac'))
+    add('finalize_traffic_over_algorithmic', rf.get('traffic_over_algorithmic'))
+    add('sustained_maps_per_s', full.get('sustained_maps_per_s'))
+    add('sustained_tap_ms', full.get('sustained_tap_ms'))
+    add('extraction_overhead_ms_per_denoise_step', full.get('extraction_overhead_ms_per_denoise_step'))
+    add('speedup_vs_eager_mi355x', full.get('speedup_vs_eager_mi355x'))
+    add('reference_eager_mi355x_maps_per_s', (full.get('reference_eager_mi355x') or {}).get('maps_per_s'))
+    for name, o in (full.get('other_configs') or {}).items():
+        ro, rfo = o.get('roofline') or {}, o.get('roofline_finalize') or {}
+        add(f'{name}_maps_per_s', o.get('value'))
+        add(f'{name}_tap_ms', ro.get('ms_per_launch'))
+        add(f'{name}_tap_frac', ro.get('frac'))
+        add(f'{name}_tap_traffic_over_algorithmic', ro.get('traffic_over_algorithmic'))
+        add(f'{name}_finalize_ms', rfo.get('ms_per_launch'))
+        add(f'{name}_finalize_frac', rfo.get('frac'))
+    add('integrated_overhead_ms_per_denoise_step', (full.get('integrated') or {}).get('overhead_ms_per_step'))
+    att = full.get('attend') or {}
+    add('attend_ms_per_denoise_step', (att.get('attend') or {}).get('ms_per_step'))
+    add('torch_sdpa_ms_per_denoise_step', (att.get('torch_sdpa') or {}).get('ms_per_step'))
+    add('gpu_bound_maps_per_s', full.get('gpu_bound_maps_per_s'))
+    add('host_enqueue_ms_per_generation', full.get('host_enqueue_ms_per_generation'))
+    if full.get('full_record'):
+        line['full_record'] = full['full_record']
+    while True:
+        s = json.dumps({**line, **dict(extras)}, allow_nan=False, separators=(', ', ': '))
+        if len(s.encode()) < LINE_LIMIT or not extras:
+            break
+        extras.pop()
+    if len(s.encode()) >= LINE_LIMIT:
+        raise SystemExit(f'bench.py: the headline line is {len(s.encode())} bytes (limit {LINE_LIMIT})')
+    return s
+
+
+def _finite(o):
+    """NaN / inf -> None, so that the records are strict JSON."""
+    if isinstance(o, float):
+        return o if o == o and abs(o) != float('inf') else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def write_full_record(full: dict):
+    """The whole measurement next to the headline line; returns the path written, or None (a read-only tree is not an error)."""
+    try:
+        path = os.path.join(ROOT, FULL_RECORD)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(full, f, allow_nan=False, indent=1)
+        return FULL_RECORD
+    except OSError as e:
+        note(f'full record not written: {e}')
+        return None
 
 
 def main():
@@ -1078,11 +1176,14 @@ def main():
                 out['roofline']['sustained_ms_per_launch'] = su['tap_ms_per_launch']
                 out['roofline']['sustained_frac'] = round(r['roofline']['bytes_per_launch'] / (su['tap_ms_per_launch'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out.update(extra)
+        out['warmup_effective'] = r['warmup_effective']
     if comm:
         comm.close()
     if rank == 0:
+        out = _finite(out)
+        out['full_record'] = write_full_record(out)
         note('done')
-        print(json.dumps(out), flush=True)
+        print(headline_line(out), flush=True)
 
 
 if __name__ == '__main__':

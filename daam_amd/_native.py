@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32,
 LIB_NAME = 'libdaam_hip.so'
 LIB_PATH = os.environ.get('DAAM_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 DAAM_F16, DAAM_F32, DAAM_BF16 = 0, 1, 2
 E_INVALID, E_STATE, E_NOMAPS, E_UNSUPPORTED = -1, -2, -3, -4
 
@@ -22,7 +22,7 @@ EXPORTS = (
     'daam_abi_version', 'daam_last_error', 'daam_ctx_create', 'daam_ctx_destroy', 'daam_layer_configure',
     'daam_layer_acc', 'daam_layer_touch', 'daam_layer_release', 'daam_reset', 'daam_tap_qk', 'daam_tap_qk_enqueue', 'daam_tap_qk_enqueue_many', 'daam_tap_pending', 'daam_tap_flush',
     'daam_tap_probs', 'daam_attend_supported', 'daam_attend', 'daam_key_offset', 'daam_finalize', 'daam_finalize_prepare', 'daam_epilogue_normalize', 'daam_word_heat_map', 'daam_mask_overlap',
-    'daam_last_launch', 'daam_last_flush', 'daam_profile_enable', 'daam_profile_last_ms', 'daam_profile_history', 'daam_clock_monitor_start', 'daam_clock_monitor_read',
+    'daam_last_launch', 'daam_last_flush', 'daam_last_kernels', 'daam_profile_enable', 'daam_profile_last_ms', 'daam_profile_history', 'daam_clock_monitor_start', 'daam_clock_monitor_read',
 )
 
 
@@ -81,8 +81,8 @@ def load() -> ctypes.CDLL:
     lib.daam_attend_supported.argtypes = [POINTER(AttendDesc), c_void_p, c_void_p, c_void_p, c_void_p]
     lib.daam_attend.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(AttendDesc), c_int, c_void_p]
     lib.daam_key_offset.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]
-    lib.daam_finalize.argtypes = [c_void_p, POINTER(c_uint8), c_void_p, c_void_p]
-    lib.daam_finalize_prepare.argtypes = [c_void_p, POINTER(c_uint8), c_void_p, c_void_p]
+    lib.daam_finalize.argtypes = [c_void_p, POINTER(c_uint8), c_int, c_void_p, c_void_p]
+    lib.daam_finalize_prepare.argtypes = [c_void_p, POINTER(c_uint8), c_int, c_void_p, c_void_p]
     lib.daam_epilogue_normalize.argtypes = [c_void_p, c_int, c_int, c_void_p]
     lib.daam_word_heat_map.argtypes = [c_void_p, c_int, POINTER(c_int32), c_int, c_void_p, c_void_p, c_int, c_int,
                                        c_int, c_float, c_void_p, c_void_p]
@@ -90,6 +90,7 @@ def load() -> ctypes.CDLL:
     lib.daam_profile_history.argtypes = [c_void_p, c_int, POINTER(c_float), c_int, POINTER(c_int)]
     lib.daam_last_launch.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     lib.daam_last_flush.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(ctypes.c_longlong)]
+    lib.daam_last_kernels.argtypes = [c_void_p, c_int, ctypes.c_char_p, c_int]
     lib.daam_profile_enable.argtypes = [c_void_p, c_int]
     lib.daam_profile_last_ms.argtypes = [c_void_p, c_int, POINTER(c_float)]
     lib.daam_clock_monitor_start.argtypes = [c_void_p, c_int, c_int]

@@ -129,15 +129,36 @@ def build_variant(out: str, flags, verbose: bool = True) -> str:
     return out
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def _deps_of(src: str) -> list:
+    """Headers / generated includes a source depends on (every HEADERS entry: they are few and cheap to stat)."""
+    return [os.path.join(HERE, 'csrc', src)] + [os.path.join(HERE, 'csrc', h) for h in HEADERS]
+
+
+def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
+    """One object per source (``daam_amd/build/*.o``, compiled in parallel, only when the source or a header is newer), one link.
+    The device code of a source is the same whether it is compiled alone or in one hipcc command with the others (no -fgpu-rdc):
+    ``kernel_shas()`` of the library is what ties profiles to a build."""
+    from concurrent.futures import ThreadPoolExecutor
     build_fastpath(force, verbose)
     if not force and not stale():
         return OUT
-    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fvisibility=hidden',
-           *[os.path.join(HERE, 'csrc', f) for f in SOURCES], '-o', OUT]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden']
+    todo = []
+    for f in SOURCES:
+        obj = os.path.join(objdir, f + '.o')
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps_of(f)):
+            todo.append([hipcc(), *flags, '-c', os.path.join(HERE, 'csrc', f), '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, todo))
+    run([hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-fvisibility=hidden',
+         *[os.path.join(objdir, f + '.o') for f in SOURCES], '-o', OUT])
     return OUT
 
 

@@ -219,6 +219,7 @@ struct DaamCtx {
     // be zeroed by the table-upload kernel of the next tap launch (fold_*)
     float* prep_out = nullptr;
     hipStream_t prep_stream = nullptr;
+    int prep_rows = 0;                 // token rows the announced call covers (= the rows that were / will be cleared)
     float* fold_out = nullptr;
     size_t fold_bytes = 0;
     hipStream_t fold_stream = nullptr;
@@ -227,6 +228,7 @@ struct DaamCtx {
     std::vector<int> pending_last;    // per layer: index of its newest entry in `pending`
     void drop_pending() { pending.clear(); pending_count.clear(); pending_last.clear(); }
     int last_grid[2] = {0, 0}, last_block[2] = {0, 0}, last_lds[2] = {0, 0};
+    std::string last_kernels[2];       // daam_last_kernels: what the last tap launch / finalize call launched, '+'-separated
     int last_fin_side = 0;             // finalize class kernels of the last call that ran on auxiliary streams
     int last_flush_kernels = 0, last_flush_side = 0, last_flush_steps = 0;   // daam_last_flush: kernels / of them on side streams / longest step chain
     long long n_flushes = 0;           // tap launches (flushes that launched something) since the context was created
@@ -391,6 +393,13 @@ static hipError_t ensure_aux(DaamCtx* c)
     }
     return ae;
 }
+
+static const char* tap_kernel_name(int kd)
+{
+    return (kd == 65 || kd == 66) ? "tap_d64_kernel" : (kd == 67 || kd == 69) ? "tap_wide_kernel" : kd == 70 ? "tap_chunk_kernel"
+           : kd == 71 ? "tap_slab_kernel" : kd ? "tap_mfma_kernel" : "tap_generic_kernel";
+}
+static const char* dtype_name(int dt) { return dt == DAAM_F32 ? "f32" : dt == DAAM_BF16 ? "bf16" : "f16"; }
 
 extern "C" {
 
@@ -774,6 +783,7 @@ int daam_tap_qk(DaamCtx* c, int layer, const void* q, const void* k, const DaamQ
                         : launch_tap_generic(L, d->in_dtype, c->acc_dtype, d->head_dim, (hipStream_t)stream,
                                              &c->last_grid[0], &c->last_lds[0]);
     if (e != hipSuccess) return fail((int)e, "tap launch: %s", hipGetErrorString(e));
+    c->last_kernels[0] = tap_kernel_name(kd1);
     c->layers[layer].dirty = true;
     c->layers[layer].zero_pending = false;
     return 0;
@@ -1131,6 +1141,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     for (size_t i = 0; i < prepared.size(); ++i)
         if (i != main_idx && !prepared[i].kd) gate = false;
     unsigned gate_wgs = 0;
+    std::string launched_names;
     for (size_t pi : launch_order) {
         if (rc) break;
         Prepared& pr = prepared[pi];
@@ -1153,6 +1164,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
                              : launch_tap_generic(pr.L, in_dtype, c->acc_dtype, pr.max_d, ks, &grid, &c->last_lds[0]);
         grid_total += grid;
         if (e != hipSuccess) { rc = fail((int)e, "tap launch: %s", hipGetErrorString(e)); break; }
+        launched_names += (launched_names.empty() ? "" : "+") + std::string(tap_kernel_name(pr.kd));
         e = c->ring.release_range(pr.ring_begin, pr.ring_end, ks);
         if (e != hipSuccess) { rc = fail((int)e, "event record: %s", hipGetErrorString(e)); break; }
         if (ks != s) {
@@ -1174,6 +1186,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     c->last_block[0] = 256;
     for (auto& pr : prepared)
         if (pr.w8 || pr.kd == 71) c->last_block[0] = 512;
+    c->last_kernels[0] = launched_names;
     c->last_flush_kernels = (int)launch_order.size();
     c->last_flush_side = n_side;
     c->last_flush_steps = 0;
@@ -1252,7 +1265,10 @@ int fin_env(const char* name)
 }
 }  // namespace
 
-static int fin_plan(DaamCtx* c, const uint8_t* key_mask, FinPlan& P)
+// token rows a finalize call covers (ABI v6: the caller may pass the prompt's n_tokens + 2, daam/trace.py:127)
+static int fin_rows(const DaamCtx* c, int n_rows) { return (n_rows <= 0 || n_rows > c->tokens) ? c->tokens : n_rows; }
+
+static int fin_plan(DaamCtx* c, const uint8_t* key_mask, int rows, FinPlan& P)
 {
     static const int env_chunks = fin_env("DAAM_FIN_CHUNKS"), env_pipe_chunks = fin_env("DAAM_FIN_PIPE_CHUNKS");   // pipelined x2 kernel only (A/B)
     auto& keys = P.keys;
@@ -1288,7 +1304,7 @@ static int fin_plan(DaamCtx* c, const uint8_t* key_mask, FinPlan& P)
     P.pipe_up = P.mfma_up && !c->no_pipe_finalize && c->d_zero_planes;
     if (P.pipe_up) {
         const int n = (int)keys[1].size();
-        const int want = env_pipe_chunks ? env_pipe_chunks : env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
+        const int want = env_pipe_chunks ? env_pipe_chunks : env_chunks ? env_chunks : std::max(1, (1024 + rows / 2) / rows);
         P.pipe_chunks = std::max(1, std::min(want, (n + 7) / 8));
         const int per = (n + P.pipe_chunks - 1) / P.pipe_chunks;
         P.pipe_nk = std::max(4, (per + 1) & ~1);
@@ -1354,22 +1370,24 @@ static int fin_cache_upload(DaamCtx* c, const FinPlan& P, hipStream_t s, void* z
     return 0;
 }
 
-static bool fin_out_zeroable(const DaamCtx* c, const float* out)
+static bool fin_out_zeroable(const DaamCtx* c, const float* out, int rows)
 {
-    const size_t out_bytes = sizeof(float) * c->tokens * (size_t)c->out_side * c->out_side;
+    const size_t out_bytes = sizeof(float) * rows * (size_t)c->out_side * c->out_side;
     return out_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
 }
 
-int daam_finalize_prepare(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
+int daam_finalize_prepare(DaamCtx* c, const uint8_t* key_mask, int n_rows, float* out, void* stream)
 {
     if (!c || !out) return fail(DAAM_E_INVALID, "NULL argument");
     DeviceGuard on_device(c);
     hipStream_t s = (hipStream_t)stream;
+    const int rows = fin_rows(c, n_rows);
     c->prep_out = c->fold_out = nullptr;
-    if (c->no_fin_cache || !fin_out_zeroable(c, out)) return 0;  // daam_finalize does everything itself
+    c->prep_rows = rows;
+    if (c->no_fin_cache || !fin_out_zeroable(c, out, rows)) return 0;  // daam_finalize does everything itself
     FinPlan P;
-    if (fin_plan(c, key_mask, P)) return 0;                      // nothing selected / unsupported: daam_finalize reports it
-    const size_t out_bytes = sizeof(float) * c->tokens * (size_t)c->out_side * c->out_side;
+    if (fin_plan(c, key_mask, rows, P)) return 0;                // nothing selected / unsupported: daam_finalize reports it
+    const size_t out_bytes = sizeof(float) * rows * (size_t)c->out_side * c->out_side;
     if (!fin_cache_hit(c, P, s)) {
         if (!fin_cacheable(c, P, s)) return 0;
         int rc = fin_cache_upload(c, P, s, out, out_bytes);      // first call of a geometry / selection: tables + zeroing now
@@ -1391,14 +1409,15 @@ int daam_finalize_prepare(DaamCtx* c, const uint8_t* key_mask, float* out, void*
     return 0;
 }
 
-int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
+int daam_finalize(DaamCtx* c, const uint8_t* key_mask, int n_rows, float* out, void* stream)
 {
     if (!c || !out) return fail(DAAM_E_INVALID, "NULL argument");
     if (!c->pending.empty()) return fail(DAAM_E_STATE, "finalize with deferred taps pending: flush first");
     DeviceGuard on_device(c);
     hipStream_t s = (hipStream_t)stream;
-    // zeroed ahead of this call (daam_finalize_prepare, same buffer, same stream)?  One-shot.
-    const bool prepared = c->prep_out == out && c->prep_stream == s;
+    const int rows = fin_rows(c, n_rows);
+    // zeroed ahead of this call (daam_finalize_prepare, same buffer, same rows, same stream)?  One-shot.
+    const bool prepared = c->prep_out == out && c->prep_stream == s && c->prep_rows == rows;
     c->prep_out = c->fold_out = nullptr;
     for (auto& l : c->layers)
         if (l.configured) {
@@ -1408,7 +1427,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     constexpr int kClasses = kFinClasses;
     FinPlan P;
     {
-        int prc = fin_plan(c, key_mask, P);
+        int prc = fin_plan(c, key_mask, rows, P);
         if (prc) return prc;
     }
     auto& keys = P.keys;
@@ -1417,11 +1436,11 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     const int pipe_chunks = P.pipe_chunks, pipe_nk = P.pipe_nk, pipe_stride = P.pipe_stride, same_per = P.same_per;
     const size_t key_bytes = P.key_bytes, ptr_bytes = P.ptr_bytes, bytes = P.tab.size();
     const size_t plane = (size_t)c->out_side * c->out_side;
-    const size_t out_bytes = sizeof(float) * c->tokens * plane;
+    const size_t out_bytes = sizeof(float) * rows * plane;
     static const int env_chunks = fin_env("DAAM_FIN_CHUNKS");
     static const int env_up_chunks = fin_env("DAAM_FIN_UP_CHUNKS");       // LDS up kernels only (A/B)
     // the output is accumulated with atomics: it is zeroed by the table-upload launch unless daam_finalize_prepare had it done
-    const bool zero_in_upload = fin_out_zeroable(c, out);
+    const bool zero_in_upload = fin_out_zeroable(c, out, rows);
     if (!zero_in_upload && !prepared) {
         hipError_t ze = hipMemsetAsync(out, 0, out_bytes, s);
         if (ze != hipSuccess) return fail((int)ze, "output memset: %s", hipGetErrorString(ze));
@@ -1464,7 +1483,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     constexpr int kFinMfmaKeysPerLaunch = kFinMaxChunks * 128;
     // x2 class chunking: ~1000 workgroups (one full round at 4 workgroups per CU) measured best -- fewer leaves a ragged
     // tail, more pays the per-workgroup reduction + atomics too often; every key lane of a chunk takes at most 64 keys
-    const int want_up = env_up_chunks ? env_up_chunks : env_chunks ? env_chunks : std::max(1, (1024 + c->tokens / 2) / c->tokens);
+    const int want_up = env_up_chunks ? env_up_chunks : env_chunks ? env_chunks : std::max(1, (1024 + rows / 2) / rows);
     // (few keys: at least 4 per wave -- a workgroup ends in a four-wave LDS reduction + 4096 atomics, which one key per wave does
     // not pay for: SD-v1.5's 48 x4 keys in 3 chunks instead of 12 take 10 us less)
     auto up_chunks = [&](int n) { return std::max(std::max(1, std::min((n + 15) / 16, want_up)), (n + 127) / 128); };
@@ -1481,7 +1500,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         L.tab_w = c->d_tab_w;
         L.out = out;
         L.n_keys = n;
-        L.tokens = c->tokens;
+        L.tokens = rows;                                       // grid dimension / bound of every class kernel; a key's planes keep their [tokens] stride
         L.out_side = c->out_side;
         L.inv_n = 1.0f / (float)total;
         L.max_side = max_side;
@@ -1537,6 +1556,10 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
         if (ae != hipSuccess || hipEventRecord(c->aux_fork, s) != hipSuccess) fork = false;    // serial launches still correct
     }
     int n_side = 0;
+    std::string launched_names;
+    auto names = [&](const char* kernel, const char* what) {
+        launched_names += (launched_names.empty() ? "" : "+") + std::string(kernel) + "<" + what + ">";
+    };
     auto launch_class = [&](int cls, hipStream_t ks, int* grid, int* lds) -> hipError_t {
         const FinLaunch& L = launches[cls];
         if (cls == 1 && pipe_up) {
@@ -1549,12 +1572,14 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             PL.n_chunks = pipe_chunks;
             PL.nk_pad = pipe_nk;
             PL.ptr_stride = pipe_stride;
-            PL.tokens = c->tokens;
+            PL.tokens = rows;
             PL.inv_n = L.inv_n;
+            names("finalize_up32_pipe_kernel", fold_same ? "f16 + same-size keys" : "f16");
             return launch_finalize_up32_pipe(PL, ks, grid);
         }
-        if (cls == 1 && paired) return launch_finalize_up32_same(L, launches[0], ks, grid);
+        if (cls == 1 && paired) { names("finalize_up32_same_kernel", "f16"); return launch_finalize_up32_same(L, launches[0], ks, grid); }
         if (cls == 1 && mfma_up) {
+            names("finalize_up32_mfma_kernel", "f16");
             hipError_t e = hipSuccess;
             for (size_t part = 0; part < up_parts.size() && e == hipSuccess; ++part) {
                 int g = 0;
@@ -1563,9 +1588,10 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
             }
             return e;
         }
-        if (cls == 0) return launch_finalize_same(L, c->acc_dtype, ks, grid);
-        if (cls == 3) return launch_finalize(L, c->acc_dtype, ks, grid, lds);
-        if (cls == 4) return launch_finalize_down2(L, c->acc_dtype, ks, grid);
+        if (cls == 0) { names("finalize_same_kernel", dtype_name(c->acc_dtype)); return launch_finalize_same(L, c->acc_dtype, ks, grid); }
+        if (cls == 3) { names("finalize_kernel", dtype_name(c->acc_dtype)); return launch_finalize(L, c->acc_dtype, ks, grid, lds); }
+        if (cls == 4) { names("finalize_down2_kernel", dtype_name(c->acc_dtype)); return launch_finalize_down2(L, c->acc_dtype, ks, grid); }
+        names(keys[cls][0].side == 32 ? "finalize_up_kernel<32>" : "finalize_up_kernel<16>", dtype_name(c->acc_dtype));
         return launch_finalize_up(L, keys[cls][0].side, c->acc_dtype, 0, ks, grid);
     };
     const int order[kClasses] = {0, 2, 3, 4, 1};                       // the x2 class last: side kernels are resident when it fills the chip
@@ -1595,6 +1621,7 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, float* out, void* stream)
     for (int i = 0; i < n_side; ++i)
         if (hipStreamWaitEvent(s, c->aux_join[i], 0) != hipSuccess) { release_tab(); return fail(DAAM_E_STATE, "stream join failed"); }
     c->last_fin_side = n_side;
+    c->last_kernels[1] = launched_names;
     if (c->profile) { (void)hipEventRecord(c->prof_event(1, 1), s); ++c->hist_count[1]; }
     release_tab();
     return 0;
@@ -1733,6 +1760,13 @@ int daam_last_flush(DaamCtx* c, int* n_kernels, int* n_side_streams, int* max_st
     if (n_side_streams) *n_side_streams = c->last_flush_side;
     if (max_steps) *max_steps = c->last_flush_steps;
     if (n_flushes) *n_flushes = c->n_flushes;
+    return 0;
+}
+
+int daam_last_kernels(DaamCtx* c, int which, char* names, int capacity)
+{
+    if (!c || !names || capacity <= 0 || which < 0 || which > 1) return fail(DAAM_E_INVALID, "bad argument");
+    snprintf(names, (size_t)capacity, "%s", c->last_kernels[which].c_str());
     return 0;
 }
 

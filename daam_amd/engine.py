@@ -364,6 +364,14 @@ class HeatMapEngine:
         nat.check(self.lib.daam_last_flush(self.ctx, ctypes.byref(k), ctypes.byref(sd), ctypes.byref(ms), ctypes.byref(n)))
         return dict(kernels=k.value, side_streams=sd.value, max_steps=ms.value, launches=n.value)
 
+    def last_kernels(self, which: int = 0) -> str:
+        """Names of the kernel(s) the last tap launch (``which`` 0) / finalize call (1) really launched (``daam_last_kernels``)."""
+        if self.ctx is None:
+            return ''
+        buf = ctypes.create_string_buffer(256)
+        nat.check(self.lib.daam_last_kernels(self.ctx, which, buf, len(buf)))
+        return buf.value.decode()
+
     def _pending(self, layer: int) -> int:
         return self._fast.pending(layer) if self._fast is not None else self._cnt[layer]
 
@@ -606,8 +614,11 @@ class HeatMapEngine:
 
     # ---- finalize ---------------------------------------------------------------------------------
     def global_heat_map(self, factors: Optional[Sequence[int]] = None, head_idx: Optional[int] = None,
-                        layer_idx: Optional[int] = None) -> torch.Tensor:
-        """trace.py:103-126: returns ``[tokens, x, x]`` fp32 on the device."""
+                        layer_idx: Optional[int] = None, n_rows: Optional[int] = None) -> torch.Tensor:
+        """trace.py:103-126: returns ``[n_rows, x, x]`` fp32 on the device.  ``n_rows`` (default: every token row) is the
+        crop of trace.py:127 applied BEFORE the work: the planes of the token rows nobody reads are neither fetched nor
+        written (``daam_finalize``'s ``n_rows``, ABI v6)."""
+        rows = self.tokens if n_rows is None else max(1, min(int(n_rows), self.tokens))
         fset = {0, 1, 2, 4, 8, 16, 32, 64} if factors is None else set(factors)
         if self.ctx is None or not self.touched:
             raise LookupError('no heat maps')
@@ -637,16 +648,16 @@ class HeatMapEngine:
         if n == 0:
             self.flush()
             raise LookupError('no heat maps')
-        out = torch.empty(self.tokens, self.out_side, self.out_side, dtype=torch.float32, device=self.device)
+        out = torch.empty(rows, self.out_side, self.out_side, dtype=torch.float32, device=self.device)
         # the output is announced BEFORE the deferred taps go out: the launch's table-upload kernel clears it and the key tables
         # stay on the device between generations, so the finalize call below is its class kernel(s) only (daam_finalize_prepare)
         optr = out.data_ptr()
 
         def announce(stream):
-            nat.check(self.lib.daam_finalize_prepare(self.ctx, mask, optr, stream))
+            nat.check(self.lib.daam_finalize_prepare(self.ctx, mask, rows, optr, stream))
         if not self.flush(_before_launch=announce):
             announce(self.stream)
-        nat.check(self.lib.daam_finalize(self.ctx, mask, optr, self.stream))
+        nat.check(self.lib.daam_finalize(self.ctx, mask, rows, optr, self.stream))
         return out
 
     def normalize_(self, maps: torch.Tensor) -> torch.Tensor:

@@ -144,14 +144,16 @@ class DiffusionHeatMapHooker(AggregateHooker):
         fp32 device tensor."""
         if prompt is None:
             prompt = self.last_prompt
+        n_rows = len(self.pipe.tokenizer.tokenize(prompt)) + 2                 # 1 for SOS and 1 for padding (trace.py:127)
         try:
-            maps = self.engine.global_heat_map(factors=factors, head_idx=head_idx, layer_idx=layer_idx)
+            # the crop is handed to the finalize: rows nobody reads are not computed (daam_finalize n_rows, ABI v6)
+            maps = self.engine.global_heat_map(factors=factors, head_idx=head_idx, layer_idx=layer_idx, n_rows=n_rows)
         except LookupError:
             if head_idx is not None or layer_idx is not None:
                 raise RuntimeError('No heat maps found for the given parameters.') from None
             raise RuntimeError('No heat maps found. Did you forget to call `with trace(...)` during generation?') \
                 from None
-        maps = maps[:len(self.pipe.tokenizer.tokenize(prompt)) + 2]            # 1 for SOS and 1 for padding
+        maps = maps[:n_rows]
         if normalize:
             maps = self.engine.normalize_(maps)
         return GlobalHeatMap(self.pipe.tokenizer, prompt, maps)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DAAM_ABI_VERSION 5
+#define DAAM_ABI_VERSION 6
 
 /* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
 #define DAAM_API __attribute__((visibility("default")))
@@ -156,18 +156,23 @@ DAAM_API int daam_attend(DaamCtx* ctx, int layer, const void* q, const void* k, 
  * compute_global_heat_map (trace.py:103-126) over the keys selected by `key_mask`:
  * HOST array, one byte per (layer, head) in layer-major order over configured layers'
  * `heads` (offset of layer l = sum of heads of layers < l, see daam_key_offset), non-zero =
- * selected.  NULL selects every key.  Writes out[tokens, out_side, out_side] fp32 =
- * mean over selected keys of clamp(bicubic(sum_plane), 0).  `out` is overwritten. */
+ * selected.  NULL selects every key.  Writes out[n_rows, out_side, out_side] fp32 =
+ * mean over selected keys of clamp(bicubic(sum_plane), 0) for the token rows [0, n_rows).
+ * `n_rows` (ABI v6): the reference crops the result to the prompt's n_tokens + 2 rows
+ * (trace.py:127), so a caller that knows the prompt passes that count and the planes of the
+ * other tokens are neither read nor written: the rows [0, n_rows) of `out` are overwritten, the
+ * rows [n_rows, tokens) -- if `out` has them at all -- are left untouched.  n_rows <= 0 or
+ * > tokens means all `tokens` rows. */
 DAAM_API int daam_key_offset(DaamCtx* ctx, int layer, int* offset, int* total);
-DAAM_API int daam_finalize(DaamCtx* ctx, const uint8_t* key_mask, float* out, void* stream);
-/* Optional, ABI v5: announce the `key_mask` / `out` / `stream` of the daam_finalize call that follows, BEFORE the deferred taps are
+DAAM_API int daam_finalize(DaamCtx* ctx, const uint8_t* key_mask, int n_rows, float* out, void* stream);
+/* Optional, ABI v5 (`n_rows`: v6): announce the `key_mask` / `n_rows` / `out` / `stream` of the daam_finalize call that follows, BEFORE the deferred taps are
  * launched (between daam_tap_qk_enqueue* and daam_tap_flush), or any time before daam_finalize when nothing is pending.  The key /
  * pointer tables of the selection are kept on the device between calls (a generation's compute_global_heat_map, trace.py:103-126,
  * selects the same keys at the same addresses as the previous one) and `out` is cleared by the table-upload kernel of the tap
  * launch, so that daam_finalize itself is its class kernel(s) only.  `out` must stay allocated and untouched until that
  * daam_finalize; the announcement is one-shot and dropped by daam_reset, by a daam_finalize with other arguments (which then does
  * everything itself, as without this call) and by the next daam_tap_flush. */
-DAAM_API int daam_finalize_prepare(DaamCtx* ctx, const uint8_t* key_mask, float* out, void* stream);
+DAAM_API int daam_finalize_prepare(DaamCtx* ctx, const uint8_t* key_mask, int n_rows, float* out, void* stream);
 
 /* trace.py:129-130: maps[:n_rows] / (maps[1:n_rows-1].sum(0) + 1e-6), in place on the first
  * n_rows planes of `maps` [*, side, side] fp32. */
@@ -203,6 +208,11 @@ DAAM_API int daam_last_launch(DaamCtx* ctx, int which /*0 tap,1 finalize*/, int*
  * step chain of the launch; `n_flushes` counts such flushes since daam_ctx_create (tests and bench.py assert the launch
  * structure a configuration is supposed to have: launches per generation, side-by-side kernels). Any pointer may be NULL. */
 DAAM_API int daam_last_flush(DaamCtx* ctx, int* n_kernels, int* n_side_streams, int* max_steps, long long* n_flushes);
+/* ABI v6: the names of the kernel(s) the last daam_tap_flush / daam_tap_qk (`which` 0) or daam_finalize (`which` 1) really launched,
+ * '+'-separated in launch order (e.g. "tap_slab_kernel", "finalize_up32_pipe_kernel<f16>+finalize_up_kernel<16>"), copied into the HOST
+ * buffer `names` (NUL-terminated, truncated to `capacity`); "" if nothing launched yet.  A report names what ran, not what the
+ * environment asked for. */
+DAAM_API int daam_last_kernels(DaamCtx* ctx, int which /*0 tap,1 finalize*/, char* names, int capacity);
 /* kernel timing for bench.py: when enabled, every tap / finalize call brackets ITS KERNEL LAUNCHES (not
  * the table upload before them) with HIP events on the call's stream; daam_profile_last_ms waits for the
  * last pair and returns the elapsed milliseconds (the only other call that synchronises the host). */

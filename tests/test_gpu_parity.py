@@ -351,21 +351,72 @@ def test_finalize_prepare_paths(monkeypatch):
             lib, stream = eng.lib, eng.stream
             A = torch.full((77, 64, 64), 7.0, device=DEV)
             B = torch.full((77, 64, 64), -3.0, device=DEV)
-            nat.check(lib.daam_finalize_prepare(eng.ctx, None, A.data_ptr(), stream))
-            nat.check(lib.daam_finalize(eng.ctx, None, B.data_ptr(), stream))
+            nat.check(lib.daam_finalize_prepare(eng.ctx, None, 0, A.data_ptr(), stream))
+            nat.check(lib.daam_finalize(eng.ctx, None, 0, B.data_ptr(), stream))
             assert torch.allclose(B, got[-1], rtol=0, atol=2e-6)
             A.fill_(9.0)
-            nat.check(lib.daam_finalize_prepare(eng.ctx, None, A.data_ptr(), stream))
-            nat.check(lib.daam_finalize(eng.ctx, None, A.data_ptr(), stream))
+            nat.check(lib.daam_finalize_prepare(eng.ctx, None, 0, A.data_ptr(), stream))
+            nat.check(lib.daam_finalize(eng.ctx, None, 0, A.data_ptr(), stream))
             assert torch.allclose(A, got[-1], rtol=0, atol=2e-6)
             # an announcement is one-shot: the next finalize into the same buffer zeroes it itself
-            nat.check(lib.daam_finalize(eng.ctx, None, A.data_ptr(), stream))
+            nat.check(lib.daam_finalize(eng.ctx, None, 0, A.data_ptr(), stream))
             assert torch.allclose(A, got[-1], rtol=0, atol=2e-6)
         eng.close()
     for g, (a, b) in enumerate(zip(results['1'], results['0'])):
         assert float(b.abs().max()) > 0
         assert torch.allclose(a, b, rtol=0, atol=2e-6), (g, float((a - b).abs().max()))
     E.release_parked_contexts()
+
+
+@pytest.mark.parametrize('sides', [(32, 64), (16, 32, 64), (128, 64), (24, 48)])
+@pytest.mark.parametrize('acc', ['float16', 'float32', 'bfloat16'])
+def test_finalize_n_rows(sides, acc):
+    """ABI v6: ``daam_finalize(..., n_rows, ...)`` computes the token rows [0, n_rows) only (the crop of daam/trace.py:127 applied before the
+    work).  For every class kernel: rows [0, n_rows) equal the oracle's / the 77-row call's, rows >= n_rows of a 77-row buffer keep
+    the sentinel they held, the announced form (daam_finalize_prepare with the same / with another row count) agrees, and the engine
+    returns an [n_rows, x, x] tensor."""
+    import ctypes
+    from daam_amd import _native as nat
+    rng = np.random.default_rng(sides[0] * 7 + len(sides))
+    out_side = 96 if 24 in sides else 64
+    heads = 3
+    eng = _engine(n_layers=len(sides), out_side=out_side, accumulate='float32' if acc == 'float32' else 'exact')
+    np_dt = ho.BF16 if acc == 'bfloat16' else acc
+    raw = []
+    for layer, side in enumerate(sides):
+        planes = rng.standard_normal((2 * heads, side * side, 77)).astype(np.float32) * 3
+        planes = ho.round_bf16(planes) if acc == 'bfloat16' else planes.astype(acc)
+        factor = out_side // side if side <= out_side else 0
+        eng.tap_probs(layer, _dev(planes, np_dt), factor=factor)
+        kept = ho.unravel(planes)
+        raw += [((factor, layer, h), kept[h]) for h in range(heads)]
+    want = ho.global_heat_map(raw, out_side * out_side)
+    tol = 3e-6 * max(1.0, np.abs(want).max())
+    full = eng.global_heat_map()
+    np.testing.assert_allclose(full.cpu().numpy(), want, rtol=0, atol=tol)
+    lib, stream = eng.lib, eng.stream
+    for n_rows in (1, 4, 12, 76, 77):
+        got = eng.global_heat_map(n_rows=n_rows)
+        assert tuple(got.shape) == (n_rows, out_side, out_side)
+        np.testing.assert_allclose(got.cpu().numpy(), want[:n_rows], rtol=0, atol=tol, err_msg=f'{sides} {acc} n_rows={n_rows}')
+        # raw ABI into a 77-row buffer of sentinels: plain call, announced call, announcement for ANOTHER row count
+        for announce in (None, n_rows, 77 if n_rows != 77 else 5):
+            buf = torch.full((77, out_side, out_side), -123.0, device=DEV)
+            if announce is not None:
+                nat.check(lib.daam_finalize_prepare(eng.ctx, None, announce, buf.data_ptr(), stream))
+                if announce != n_rows:
+                    torch.cuda.synchronize()
+                    buf.fill_(-123.0)                      # what the announcement cleared is not this call's business
+            nat.check(lib.daam_finalize(eng.ctx, None, n_rows, buf.data_ptr(), stream))
+            np.testing.assert_allclose(buf[:n_rows].cpu().numpy(), want[:n_rows], rtol=0, atol=tol,
+                                       err_msg=f'{sides} {acc} n_rows={n_rows} announce={announce}')
+            assert bool((buf[n_rows:] == -123.0).all()), (sides, acc, n_rows, announce)
+    # out of range = every row
+    buf = torch.full((77, out_side, out_side), -123.0, device=DEV)
+    nat.check(lib.daam_finalize(eng.ctx, None, 500, buf.data_ptr(), stream))
+    np.testing.assert_allclose(buf.cpu().numpy(), want, rtol=0, atol=tol)
+    assert eng.last_kernels(1) != ''
+    eng.close()
 
 
 def test_raw_abi_strides_past_32_bit_offsets_fall_back():

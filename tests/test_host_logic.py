@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == sorted(_native.EXPORTS), 'include/daam_hip.h and daam_amd/_native.py disagree'
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.daam_abi_version() == _native.ABI_VERSION == 5
+    assert lib.daam_abi_version() == _native.ABI_VERSION == 6
     assert ctypes.sizeof(_native.QKDesc) == 80          # 8 x 4 bytes + 6 x 8 bytes, no padding surprises
     # built with -fvisibility=hidden: the only FUNCTIONS the library exports are the C ABI (the remaining dynamic
     # symbols are the device-kernel handles the HIP runtime registers)
