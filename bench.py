@@ -1025,11 +1025,12 @@ def _finite(o):
 def write_full_record(full: dict):
     """The whole measurement next to the headline line; returns the path written, or None (a read-only tree is not an error)."""
     try:
-        path = os.path.join(ROOT, FULL_RECORD)
+        rel = os.environ.get('BENCH_FULL_RECORD', FULL_RECORD)      # (tests running several benches side by side give each its own file)
+        path = rel if os.path.isabs(rel) else os.path.join(ROOT, rel)
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, 'w') as f:
             json.dump(full, f, allow_nan=False, indent=1)
-        return FULL_RECORD
+        return rel
     except OSError as e:
         note(f'full record not written: {e}')
         return None

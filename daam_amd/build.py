@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['daam_api.hip', 'daam_kernels.hip', 'daam_tap_mfma.hip', 'daam_tap_d64.hip', 'daam_tap_wide.hip', 'daam_tap_chunk.hip', 'daam_tap_slab.hip', 'daam_attend_d64.hip', 'daam_finalize.hip', 'daam_finalize_pipe.hip']
-HEADERS = ['daam_types.h', 'daam_tap_common.h', 'daam_tap16.h', 'daam_tap16_softmax.h', 'daam_finalize_pipe_asm_r16.inc', 'daam_finalize_pipe_prefill_r16.inc', 'daam_finalize_pipe_asm_r8.inc', 'daam_finalize_pipe_prefill_r8.inc', os.path.join('..', '..', 'include', 'daam_hip.h')]
+HEADERS = ['daam_types.h', 'daam_tap_common.h', 'daam_tap16.h', 'daam_tap16_softmax.h', 'daam_finalize_pipe_asm_r16.inc', 'daam_finalize_pipe_prefill_r16.inc', os.path.join('..', '..', 'include', 'daam_hip.h')]
 OUT = os.path.join(HERE, 'libdaam_hip.so')
 
 

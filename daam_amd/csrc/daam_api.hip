@@ -210,9 +210,6 @@ struct DaamCtx {
     std::vector<char> fin_tab_host;   // the bytes d_fin_tab holds (when fin_tab_valid)
     bool fin_tab_valid = false;
     hipStream_t fin_tab_stream = nullptr;   // the stream its upload and its readers were enqueued on
-    int tap_head_minor = 0;           // DAAM_TAP_HEAD_MINOR=1: head-minor workgroup numbering of the head_dim-64 deferred launches (A/B)
-    int tap_q2 = 0;                   // DAAM_TAP_Q2=1: eight-wave head_dim-64 launches request half of every Q tile two steps ahead (round 5: built on the verdict's
-                                      // advice, bit-identical, measured 1.3 % SLOWER on the headline -- 491-493 against 498 maps/s alternating on one box -- so it is opt-in)
     int no_w8 = 0;                    // debugging / A-B: DAAM_TAP_W8=0 (head_dim-64 launches on 4-wave workgroups of 128 pixels instead of 8-wave / 256)
     int no_fin_cache = 0;             // debugging / A-B: DAAM_NO_FIN_CACHE=1 (tables through the ring + zeroing in every call)
     // daam_finalize_prepare: the output buffer the next daam_finalize accumulates into has been zeroed already (prep_*), or is to
@@ -446,10 +443,6 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
     c->no_paired_finalize = npf && npf[0] == '1';
     const char* w8 = getenv("DAAM_TAP_W8");
     c->no_w8 = w8 && w8[0] == '0';
-    const char* hm = getenv("DAAM_TAP_HEAD_MINOR");
-    c->tap_head_minor = hm && hm[0] == '1';
-    const char* q2 = getenv("DAAM_TAP_Q2");
-    c->tap_q2 = q2 && q2[0] == '1';
     const char* nfc = getenv("DAAM_NO_FIN_CACHE");
     c->no_fin_cache = nfc && nfc[0] == '1';
     const char* n16 = getenv("DAAM_NO_D64");            // debugging: 32x32-tile kernel also for head_dim 64
@@ -465,10 +458,9 @@ int daam_ctx_create(int max_layers, int tokens, int out_side, int acc_dtype, Daa
 
     // softmax flavour of the MFMA tap: fast (default; exponent by one mixed-precision FMA, ~1e-6 relative,
     // same deviation class as the f32 summation order of q.k -- DESIGN.md section 3.1) or compensated
-    // (DAAM_STRICT_EXP=1 / DAAM_FAST_EXP=0: ~1 ulp f32 like the reference's expf)
-    const char* fe = getenv("DAAM_FAST_EXP");
+    // (DAAM_STRICT_EXP=1: ~1 ulp f32 like the reference's expf)
     const char* se = getenv("DAAM_STRICT_EXP");
-    c->fast_exp = !((se && se[0] == '1') || (fe && fe[0] == '0'));
+    c->fast_exp = !(se && se[0] == '1');
     *out = c;
     return 0;
 }
@@ -1078,7 +1070,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         pr.L.wgs_per_xcd = (wg + 7) / 8;
         pr.L.n_seg = n_seg;
         for (int k = 0; k < 5; ++k) pr.L.seg_begin[k] = seg_begin[k];
-        pr.L.head_minor = ((kd == 65 || kd == 66) && c->tap_head_minor) ? 1 : 0;
+        pr.L.head_minor = 0;
         pr.max_d = max_d;
         pr.min_d = min_d;
         pr.all_round = all_round;
@@ -1108,11 +1100,9 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         else forked = true;
     }
     std::vector<size_t> launch_order;                        // side kinds first, the main one last
-    static const bool main_first = getenv("DAAM_TAP_MAIN_FIRST") && getenv("DAAM_TAP_MAIN_FIRST")[0] == '1';   // A/B switch
-    if (forked && main_first) launch_order.push_back(main_idx);
     for (size_t i = 0; i < prepared.size(); ++i)
         if (!forked || i != main_idx) launch_order.push_back(i);
-    if (forked && !main_first) launch_order.push_back(main_idx);
+    if (forked) launch_order.push_back(main_idx);
     int n_side = 0;
     // start gate: the side kernels' workgroups count themselves in, the main kernel waits (one wave, bounded) until they are
     // resident -- only for the kernels that carry the counter (the MFMA kinds)
@@ -1137,7 +1127,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             }
         }
     }
-    bool gate = forked && !main_first && !c->no_start_gate && !c->gate_off_until && c->d_started;
+    bool gate = forked && !c->no_start_gate && !c->gate_off_until && c->d_started;
     for (size_t i = 0; i < prepared.size(); ++i)
         if (i != main_idx && !prepared[i].kd) gate = false;
     unsigned gate_wgs = 0;
@@ -1156,7 +1146,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             if (ge != hipSuccess) { rc = fail((int)ge, "start gate: %s", hipGetErrorString(ge)); break; }
         }
         int grid = 0;
-        hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, pr.w8 ? (c->tap_q2 ? 2 : 1) : 0, ks, &grid, &c->last_lds[0])
+        hipError_t e = (pr.kd == 65 || pr.kd == 66) ? launch_tap_d64(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d == 64 && pr.max_d == 64, pr.w8 ? 1 : 0, ks, &grid, &c->last_lds[0])
                      : (pr.kd == 67 || pr.kd == 69) ? launch_tap_wide(pr.L, c->acc_dtype, pr.max_d, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])
                      : pr.kd == 70 ? launch_tap_chunk(pr.L, in_dtype, c->acc_dtype, c->fast_exp && pr.all_round, pr.min_d != pr.max_d, ks, &grid, &c->last_lds[0])
                      : pr.kd == 71 ? launch_tap_slab(pr.L, c->acc_dtype, c->fast_exp && pr.all_round, ks, &grid, &c->last_lds[0])

@@ -19,17 +19,8 @@
 // tap a [77][128] fp16 tile of probabilities that turns the lanes' scattered 2-byte values into 16-byte row pieces of the sums.
 #include "daam_tap16_softmax.h"
 
-// Experiment kept as a compile-time switch (-DDAAM_ATTEND_QLDS=1; round 5, on the round-4 verdict's advice): Q of the head_dim <= 64 shape
-// (KS == 2: SDXL, SD-2.x, SD-v1.5's 64 x 64 layers) through LDS in FULL 128-byte rows -- a wave's 32 pixel rows by LDS-DMA (four
-// wave-instructions of 8 whole rows, 16-byte pieces XOR-swizzled on the source address, like the tap kernels) into the corner of LDS that
-// later holds the tap's probability tile, operands by conflict-free ds_read_b128 -- instead of 16-byte fragment loads (16 rows x 64 B per
-// instruction: 16 bytes per L1 tag lookup, the pattern the tap left in round 2).  Correct (tests/test_gpu_attend.py, test_gpu_processor.py:
-// 70 tests) and 5 % SLOWER: 0.514 against 0.490 ms per 60-call SDXL step, alternating on one box (gpurun_out/r5_5_attend_*.json) -- the
-// call is one pass and latency-bound, and the LDS hop (DMA lands -> wait -> ds_read) is a longer way to the first MFMA than a register
-// load.  What helped the 50-step tap loop (TA throughput) does not help a kernel that issues each load once.
-#ifndef DAAM_ATTEND_QLDS
-#define DAAM_ATTEND_QLDS 0
-#endif
+// (Q through full 128-byte LDS rows by LDS-DMA, as in the tap kernels, was built in round 5 and measured 5 % slower -- the call is one pass and
+// latency-bound; the variant is a patch under tools/exp/patches/, LABNOTES R5.6.)
 
 namespace daam {
 
@@ -133,22 +124,7 @@ __global__ __launch_bounds__(256, 2) void attend_kernel(const AttendLaunch L)
     }
     const int px[2] = {p0 + wave * 32 + j, p0 + wave * 32 + 16 + j};
     half8 qreg[2][KS];
-    constexpr bool kQLds = DAAM_ATTEND_QLDS != 0 && KS == 2;
-    // (the probability tile's space: nothing is written there before the barrier behind the K / V commit, and this wave has its
-    // operands in registers by then)
-    [[maybe_unused]] unsigned char* qtile = smem + S::kStageOff + wave * (32 * 128);
-    if constexpr (kQLds) {
-        typedef __attribute__((address_space(3))) void* lds_ptr_t;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // instruction i: rows 8 i .. 8 i + 7 of the wave's tile (LDS image lane-linear: slot lane & 7 of row 8 i + (lane >> 3));
-            // slot s of row r holds source piece s ^ ((r >> 1) & 7); pieces past head_dim re-read piece 0 (cleared after the operand read)
-            const int r = 8 * i + (lane >> 3);
-            const int ch = (lane & 7) ^ ((r >> 1) & 7);
-            const char* src = qp + ((int64_t)min(p0 + wave * 32 + r, L.hw - 1) * L.q_sp + (ch * 8 < d ? ch * 8 : 0)) * 2;
-            __builtin_amdgcn_global_load_lds((const DAAM_GLOBAL void*)src, (lds_ptr_t)(qtile + i * 1024), 16, 0, 0);
-        }
-    } else {
+    {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const char* row = qp + (int64_t)min(px[g], L.hw - 1) * L.q_sp * 2;
@@ -200,19 +176,6 @@ __global__ __launch_bounds__(256, 2) void attend_kernel(const AttendLaunch L)
 #pragma unroll
             for (int i = 0; i < 8; ++i) *reinterpret_cast<_Float16*>(col + i * kVRow) = vv[i];
         }
-    }
-    if constexpr (kQLds) {
-        // this wave's Q rows have landed (the K / V commit above waited for every fetch of the wave); operands -> registers BEFORE the
-        // barrier, behind which other waves may write probabilities over the tile
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int e = 32 * ks + 8 * h;
-                qreg[g][ks] = *reinterpret_cast<const half8*>(qtile + (16 * g + j) * 128 + (((4 * ks + h) ^ ((j >> 1) & 7)) << 4));
-                if (e >= d) qreg[g][ks] = half8{0, 0, 0, 0, 0, 0, 0, 0};           // zero-padded contraction
-            }
     }
     __syncthreads();
 

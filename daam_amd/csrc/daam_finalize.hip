@@ -15,14 +15,6 @@
 
 namespace daam {
 
-// debug aid (tools/exp/fin_timing.py; build with -DDAAM_FIN_TIMING): per-workgroup phase timestamps of the x2 MFMA kernel
-#ifdef DAAM_FIN_TIMING
-__device__ unsigned long long daam_fin_dbg[1024][4];
-#define DAAM_FT(i) do { if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1024) \
-    daam_fin_dbg[blockIdx.y * gridDim.x + blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define DAAM_FT(i) do {} while (0)
-#endif
 
 
 typedef float float4v __attribute__((ext_vector_type(4)));
@@ -314,13 +306,9 @@ __device__ __forceinline__ float fin_max_nonneg(float a, float b) {
 // consumed only by the next MFMA of the chain, which takes it whole as C (no wait states needed); everything that READS
 // an MFMA result with the VALU is compiler-generated code (no inline asm), so those wait states are padded for us.
 __device__ __forceinline__ floatx16 fin_mfma_from(const half8& a, const half8& b, const floatx16& c) {
-#ifdef DAAM_FIN_TIED_MFMA
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-#else
     floatx16 d;
     asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
-#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -424,14 +412,8 @@ __global__ __launch_bounds__(256) void finalize_down2_kernel(const FinLaunch L)
     wg_reduce_flush(red, wave, get, add, [&](int i) { return i * O + lane; }, L.out + (size_t)tok * O * O, L.inv_n);
 }
 
-// tunables of the x2 MFMA kernel (overridable for A/B builds): planes prefetched ahead per wave, waves per SIMD the register
-// allocator must leave room for
-#ifndef DAAM_FIN_KDEPTH
-#define DAAM_FIN_KDEPTH 2
-#endif
-#ifndef DAAM_FIN_WAVES
-#define DAAM_FIN_WAVES 4
-#endif
+// tunables of the x2 MFMA kernel: planes prefetched ahead per wave, waves per SIMD the register allocator must leave room for
+constexpr int kFinKDepth = 2, kFinWaves = 4;
 
 // body: workgroup (tok, chunk) of n_chunks key chunks
 __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, const int tok, const int chunk, const int n_chunks)
@@ -440,7 +422,7 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
     // output per wave keeps the kernel under 128 VGPRs (4 waves per SIMD: the MFMA chain of one wave
     // runs under the VALU work of the others); the plane is fetched by both nt waves (second one hits L2).
     constexpr int S = 32, O = 64;
-    constexpr int kDepth = DAAM_FIN_KDEPTH, kMaxKeysPerWave = 64;
+    constexpr int kDepth = kFinKDepth, kMaxKeysPerWave = 64;
     __shared__ const void* kbase[2][kMaxKeysPerWave];
     __shared__ __align__(16) float red[2][32 * 64];
 
@@ -448,7 +430,6 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: loop bounds and branches stay scalar
     const int n = lane & 31, g = lane >> 5;
     const int nt = wave & 1, kq = wave >> 1;
-    DAAM_FT(0);
 
     // operand pieces of the banded tap matrix, built on the host (build_up32_ops in daam_api.hip):
     //   wx[ks][e]    = W[32nt + n][16ks + 8g + e]                              (B of pass 1)
@@ -467,7 +448,6 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
     if (nt == 0 && lane < nk) kbase[kq][lane] = as_global<FinKey>(L.keys)[first + lane * stride].base;
     __syncthreads();
 
-    DAAM_FT(1);
     half8 pre[kDepth][2];
     auto fetch = [&](int i, half8 (&dst)[2]) {
         const _Float16* src = reinterpret_cast<const _Float16*>(kbase[kq][i]) + (size_t)tok * S * S + n * S + 8 * g;
@@ -496,9 +476,7 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
     auto plane_step = [&](int ki, half8 (&p)[2], half8 (&p_next)[2]) {
         floatx16 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(p[0], wx[0], floatx16{0}, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(p[1], wx[1], c, 0, 0, 0);
-#if !defined(DAAM_FIN_ABLATE) || DAAM_FIN_ABLATE != 1       // experiment 1: no plane fetches after the first kDepth
         fetch(min(ki + kDepth, last), p);
-#endif
         half8 bhi[2], blo[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -540,7 +518,6 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
 #pragma unroll
     for (int d = 0; d < kDepth - 1; ++d)                      // remainder (nk not a multiple of kDepth): slots 0 .. in order
         if (ki + d < nk) plane_step(ki + d, pre[d], pre[(d + 1) % kDepth]);
-    DAAM_FT(2);
     // the two key halves of an nt tile meet in LDS; the kq = 0 wave adds the sum into the output
     if (kq == 1) {
 #pragma unroll
@@ -557,21 +534,13 @@ __device__ __forceinline__ void finalize_up32_mfma_body(const FinLaunch& L, cons
             atomicAdd(out + row * O, (acc[i >> 4][i & 15] + red[nt][i * 64 + lane]) * L.inv_n);
         }
     }
-    DAAM_FT(3);
 }
 
-__global__ __launch_bounds__(256, DAAM_FIN_WAVES) void finalize_up32_mfma_kernel(const FinLaunch L)
+__global__ __launch_bounds__(256, kFinWaves) void finalize_up32_mfma_kernel(const FinLaunch L)
 {
     finalize_up32_mfma_body(L, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
-#ifdef DAAM_FIN_TIMING
-}  // namespace daam
-extern "C" __attribute__((visibility("default"))) int daam_debug_dump_fin(unsigned long long* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(daam::daam_fin_dbg), sizeof(daam::daam_fin_dbg));
-}
-namespace daam {
-#endif
 
 // side == out_side: out[t][i] += sum over this chunk's keys of max(plane[t][i], 0) / N.
 // A wave owns 64 consecutive 16-byte pieces of one token plane; kBatch keys are in flight per
@@ -637,7 +606,7 @@ struct FinPair {
     int32_t up_blocks, same_gx, same_gy;
 };
 
-__global__ __launch_bounds__(256, DAAM_FIN_WAVES) void finalize_up32_same_kernel(const FinPair P)
+__global__ __launch_bounds__(256, kFinWaves) void finalize_up32_same_kernel(const FinPair P)
 {
     const int b = blockIdx.x;
     if (b < P.up_blocks) {

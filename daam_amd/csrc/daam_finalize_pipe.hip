@@ -24,28 +24,11 @@
 
 namespace daam {
 
-// debug aid (tools/exp/pipe_timing.py; build with -DDAAM_PIPE_TIMING): per-wave phase timestamps (100 MHz reference counter)
-#ifdef DAAM_PIPE_TIMING
-__device__ unsigned long long daam_pipe_dbg[4096][8];     // [0..5] phase stamps (100 MHz), [6..7] shader-cycle counter around the loop
-#define DAAM_PT(i) do { if ((threadIdx.x & 63) == 0) { const unsigned w_ = (blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 6); \
-    if (w_ < 4096) daam_pipe_dbg[w_][i] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define DAAM_PT(i) do {} while (0)
-#endif
-#ifdef DAAM_PIPE_TIMING
-#define DAAM_PC(i) do { if ((threadIdx.x & 63) == 0) { const unsigned w_ = (blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 6); \
-    if (w_ < 4096) daam_pipe_dbg[w_][i] = __builtin_amdgcn_s_memtime(); } } while (0)
-#else
-#define DAAM_PC(i) do {} while (0)
-#endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-#ifndef DAAM_PIPE_RING
-#define DAAM_PIPE_RING 16               // planes per workgroup ring: 8 or 16 (a generated schedule per depth, tools/gen_fin_pipe.py)
-#endif
-constexpr int kPipeRing = DAAM_PIPE_RING;
+constexpr int kPipeRing = 16;              // planes per workgroup ring (the generated schedule is per depth: tools/gen_fin_pipe.py)
 constexpr int kSameBatch = 8;           // same-size keys whose pieces are fetched together (32 loads in flight per lane)
 constexpr int kPipePlane = 32 * 32 * 2; // bytes
 
@@ -60,7 +43,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 {
     __shared__ __align__(16) unsigned char ring[kPipeRing * kPipePlane];         // 16 KiB, shared by the workgroup's two waves
 
-    DAAM_PT(0);
     if (L.nk_pad < 4 || (L.nk_pad & 1)) return;               // the pipeline's prologue / drain assume >= 4 planes, an even count (host-padded)
     const int lane = threadIdx.x & 63;
     const int nt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -75,14 +57,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)(&ring[0]));
     const unsigned ring_half = ring_base + (unsigned)nt * 1024u;
     const unsigned lds_rd = ring_base + (unsigned)n * 64u + (unsigned)g * 16u;    // A piece: row n, columns 8g.. (+32 bytes: 16 + 8g..)
-#if defined(DAAM_PIPE_ABLATE)
-#include "daam_finalize_pipe_prefill_ablx.inc"
-#elif DAAM_PIPE_RING == 16
 #include "daam_finalize_pipe_prefill_r16.inc"
-#else
-#include "daam_finalize_pipe_prefill_r8.inc"
-#endif
-    DAAM_PT(1);
 
     // ---- the same-size (64 x 64) keys of the selection, under the latency of the ring's first planes ------------------
     // out += max(P, 0) for this wave's 32 columns of every row, straight into the accumulators of the pipeline (C/D layout:
@@ -142,7 +117,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     };
     if (same_first) same_size_keys();
-    DAAM_PT(2);
     // operand pieces of the banded tap matrix, built on the host (build_up32_ops in daam_api.hip):
     //   wx[ks][e]    = W[32nt + n][16ks + 8g + e]                              (B of pass 1)
     //   wy[t][ks][i] = W[32t + n][16ks + 8(i >> 2) + 4g + (i & 3)]             (A of pass 2, permuted k)
@@ -152,28 +126,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     int trips = __builtin_amdgcn_readfirstlane((L.nk_pad - 2) >> 1);              // steady-state loop trips, 2 planes each
     floatx16 accB0, accB1;                                                       // odd planes
-    DAAM_PT(3);
-    DAAM_PC(6);
-#if defined(DAAM_PIPE_ABLATE)                                 // timing experiments (tools/gen_fin_pipe.py), results are wrong
-#if DAAM_PIPE_ABLATE == 1
-#include "daam_finalize_pipe_asm_abl1.inc"
-#elif DAAM_PIPE_ABLATE == 2
-#include "daam_finalize_pipe_asm_abl2.inc"
-#elif DAAM_PIPE_ABLATE == 3
-#include "daam_finalize_pipe_asm_abl3.inc"
-#elif DAAM_PIPE_ABLATE == 4
-#include "daam_finalize_pipe_asm_abl4.inc"
-#else
-#include "daam_finalize_pipe_asm_abl5.inc"
-#endif
-#elif DAAM_PIPE_RING == 16
 #include "daam_finalize_pipe_asm_r16.inc"
-#else
-#include "daam_finalize_pipe_asm_r8.inc"
-#endif
 
-    DAAM_PC(7);
-    DAAM_PT(4);
     if (!same_first) same_size_keys();
     // C/D layout: lane (n, g) owns out[32 mt + 8 b + 4 g + r][32 nt + n] in register 4 b + r of tile mt
     float* out = L.out + (size_t)tok * 64 * 64 + 32 * nt + n;
@@ -183,7 +137,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float v = (i < 16 ? accA0[i & 15] + accB0[i & 15] : accA1[i & 15] + accB1[i & 15]);
         atomicAdd(out + row * 64, v * L.inv_n);
     }
-    DAAM_PT(5);
 }
 
 hipError_t launch_finalize_up32_pipe(const FinPipeLaunch& L, hipStream_t stream, int* grid_out)
@@ -198,8 +151,3 @@ int finalize_pipe_ring() { return kPipeRing; }
 
 }  // namespace daam
 
-#ifdef DAAM_PIPE_TIMING
-extern "C" __attribute__((visibility("default"))) int daam_debug_dump_pipe(unsigned long long* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(daam::daam_pipe_dbg), sizeof(daam::daam_pipe_dbg));
-}
-#endif

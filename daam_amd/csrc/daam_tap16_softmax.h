@@ -189,16 +189,10 @@ __device__ __forceinline__ void softmax20_probs_fast(const floatx4 (&c)[5], floa
         float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < kSlots16 / 2; i += 2) {
-#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 4            // timing experiment 4: no v_exp_f32 (results are wrong)
-#define DAAM_EXP2(x) (x)
-#else
-#define DAAM_EXP2(x) __builtin_amdgcn_exp2f(x)
-#endif
-            ev[i] = float2v{DAAM_EXP2(__builtin_fmaf((float)xh[i][0], L, nmL)),
-                            DAAM_EXP2(__builtin_fmaf((float)xh[i][1], L, nmL))};
-            ev[i + 1] = float2v{DAAM_EXP2(__builtin_fmaf((float)xh[i + 1][0], L, nmL)),
-                                DAAM_EXP2(__builtin_fmaf((float)xh[i + 1][1], L, nmL))};
-#undef DAAM_EXP2
+            ev[i] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][0], L, nmL)),
+                            __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i][1], L, nmL))};
+            ev[i + 1] = float2v{__builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][0], L, nmL)),
+                                __builtin_amdgcn_exp2f(__builtin_fmaf((float)xh[i + 1][1], L, nmL))};
             sa += ev[i];
             sb += ev[i + 1];
         }
@@ -210,9 +204,6 @@ __device__ __forceinline__ void softmax20_probs_fast(const floatx4 (&c)[5], floa
     float no_shift = 0.f;
     asm("" : "+v"(no_shift));
     float tot = exps(no_shift);
-#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 4
-    tot = 1.0f + tot * 0.f;                                             // (the ablated "exponentials" sum to anything: never the slow path)
-#endif
     if (__builtin_expect(softmax_sum_out_of_range(tot), 0)) {           // huge, tiny, inf or NaN
         half2v ma = xh[0], mb = xh[1];
 #pragma unroll

@@ -21,16 +21,6 @@
 // registers after the LDS read (K x 0 = 0); a k-step that lies entirely past head_dim is skipped.
 #include "daam_tap16_softmax.h"
 
-// Debug aid (tools/exp/chunk_timeline.py; build with -DDAAM_CHUNK_TIMING): per-workgroup stamps -- 100 MHz reference counter at the start,
-// at the first step, after the last step and at the end; shader cycles wave 0 spent in the per-sub-step DMA wait + barrier and in the
-// whole loop; head_dim; HW_ID.
-#ifdef DAAM_CHUNK_TIMING
-__device__ unsigned long long daam_chunk_dbg[4096][8];
-#define DAAM_CT(i, v) do { if (threadIdx.x == 0 && wg < 4096) daam_chunk_dbg[wg][i] = (v); } while (0)
-#else
-#define DAAM_CT(i, v) do {} while (0)
-#endif
-
 namespace daam {
 
 constexpr int kCkRow = 128;                         // bytes per K / Q row in LDS: one 64-element chunk, 16-byte pieces swizzled
@@ -103,7 +93,6 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     if (L.wgs_per_xcd > 0) wg = mfma_logical_block(L.total_wgs, L.wgs_per_xcd);
     else wg = (int)blockIdx.x < L.total_wgs ? (int)blockIdx.x : -1;
     if (wg < 0) return;
-    DAAM_CT(0, __builtin_amdgcn_s_memrealtime());
     tap_mark_started(L);
     TapLayer lay;
     const bool table = L.layers != nullptr;
@@ -240,31 +229,17 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
     const floatx4 cmask = premask_tile4(h);
     dma(0, 0, 0);
     int buf = 0;
-#ifdef DAAM_CHUNK_TIMING
-    unsigned long long waited = 0, w0 = 0;
-    const unsigned long long loop0 = __builtin_amdgcn_s_memtime();
-    DAAM_CT(1, __builtin_amdgcn_s_memrealtime());
-#define DAAM_CW0() w0 = __builtin_amdgcn_s_memtime()
-#define DAAM_CW1() waited += __builtin_amdgcn_s_memtime() - w0
-#else
-#define DAAM_CW0() do {} while (0)
-#define DAAM_CW1() do {} while (0)
-#endif
     for (int s = 0; s < n_steps; ++s) {
         floatx4 c0[5], c1[5];
         const int s_next = min(s + 1, n_steps - 1);           // branch-free: the last step re-fetches itself
-        DAAM_CW0();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        DAAM_CW1();
         chunk_mfma<IN, true>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && n_ch == 1, vc, h, c0, c1, cmask);
         buf ^= 1;
         if (n_ch > 1) dma(s, 1, buf); else dma(s_next, 0, buf);
         for (int c = 1; c < n_ch; ++c) {
-            DAAM_CW0();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            DAAM_CW1();
             chunk_mfma<IN, false>(kbuf + buf * kCkKBuf, qtile, f_rd, last_partial && c == n_ch - 1, vc, h, c0, c1, cmask);
             buf ^= 1;
             if (c + 1 < n_ch) dma(s, c + 1, buf); else dma(s_next, 0, buf);
@@ -277,18 +252,6 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             softmax20_accumulate<ACC_T, FAST_EXP, true>(c1, lay, h, run1);
         }
     }
-#ifdef DAAM_CHUNK_TIMING
-    DAAM_CT(2, __builtin_amdgcn_s_memrealtime());
-    DAAM_CT(4, waited);
-    DAAM_CT(5, __builtin_amdgcn_s_memtime() - loop0);
-    DAAM_CT(6, (unsigned long long)d | ((unsigned long long)n_steps << 16));
-    {
-        unsigned hw_id, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        DAAM_CT(7, (unsigned long long)hw_id | ((unsigned long long)xcc << 32));
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last (redundant) fetch has landed before the staging tile reuses the space
     __syncthreads();                                          // all K reads done
 
@@ -308,7 +271,6 @@ __global__ __launch_bounds__(256, ((sizeof(ACC_T) == 2 && !IN::kBf16) ? 4 : 3)) 
             *as_global_rw<float4v>(acc + (size_t)row * lay.hw + p0 + col) =
                 *reinterpret_cast<const float4v*>(stage + row * kMfmaPixels + col);
     }
-    DAAM_CT(3, __builtin_amdgcn_s_memrealtime());
 }
 
 // q_extent = elements from the tensor's first to past its last addressed Q element (batch * q_sb): byte offsets stay in 32 bits
@@ -368,8 +330,3 @@ hipError_t launch_tap_chunk(const TapLaunch& L0, int in_dtype, int acc_dtype, in
 
 }  // namespace daam
 
-#ifdef DAAM_CHUNK_TIMING
-extern "C" __attribute__((visibility("default"))) int daam_debug_dump_chunk(unsigned long long* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(daam_chunk_dbg), sizeof(daam_chunk_dbg));
-}
-#endif

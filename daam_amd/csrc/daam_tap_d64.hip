@@ -12,7 +12,7 @@
 //   logits = fp16(f32(q.k) * scale) -> f32 softmax -> fp16(p) -> acc += p (accumulator dtype).
 //
 // Workgroup = 4 waves = 128 pixels of one (layer, kept head) -- or, for head_dim-64 launches with fp16 sums since round 4, 8 waves = 256
-// pixels sharing ONE K tile (template parameter WAVES, DAAM_TAP_W8 below); wave w: pixels
+// pixels sharing ONE K tile (template parameter WAVES); wave w: pixels
 // [32w, 32w+32) = groups 0 / 1 of 16.  "Swapped" product S^T = K Q^T: A = K rows (lane: token row
 // l&15 of the 16-row tile, k = 8*(l>>4)..+7 of the 32-wide k-step), B = Q^T (lane: pixel l&15, same
 // k split).  C/D: lane holds pixel l&15 and tokens 16*mt + 4*(l>>4) + r (mt = 0..4, r = 0..3) = 20 slots.
@@ -26,48 +26,15 @@
 // lookup -- 0.67 lookups per cycle per CU and a read-tag-conflict stall in 20 % of the cycles
 // (TCP_TOTAL_CACHE_ACCESSES, TCP_READ_TAGCONFLICT_STALL_CYCLES; profiles/r02_tap_tcp.txt).
 #include "daam_tap16_softmax.h"
-#include <type_traits>
 
-// cache policy of the Q fetches (every Q row is read exactly once per launch): 0 = default, 2 = non-temporal (A/B: -DDAAM_TAP_Q_AUX=2)
-#ifndef DAAM_TAP_Q_AUX
-#define DAAM_TAP_Q_AUX 0
-#endif
-// K and Q of head_dim-64 launches (FULL64: every SDXL / SD-2.x layer) go HBM -> LDS by LDS-DMA (buffer_load ... lds: the swizzle is
-// applied to the SOURCE address, the LDS image of a wave-instruction is lane-linear) instead of through staging registers +
-// ds_write_b128: seven ds_write_b128 and 24 VGPRs fewer per lane-step (122 -> 98).  Round 3, on the full-row data path: +0.7 ... +2.4 %
-// heat maps / s depending on the box (round 1 measured the DMA form 10 % SLOWER on the fragment-shaped path).  One K buffer + a second
-// barrier (27 KB of LDS, 5 waves per SIMD) measured the same as two.  -DDAAM_TAP_DMA=0 brings the register-staged form back for A/B
-// runs; head_dim < 64 (zero-padded chunks cannot come from a DMA) always takes it.
-#ifndef DAAM_TAP_DMA
-#define DAAM_TAP_DMA 1
-#endif
-// the next step's DMAs ahead of this step's MFMAs instead of behind them (K: right after the barrier, its other buffer is free; Q: once
-// the wave's four operand reads have returned) -- ~0.3 us more for a fetch to land.  Round 4: the launch sits on the floor of its data
-// path (the same launch WITHOUT softmax and MFMAs takes as long, LABNOTES R4.6), and this buys 0.5-0.8 % on it; -DDAAM_TAP_EARLY_DMA=0
-// for A/B runs.  (Tried on top, measured and removed: half of every second step's Q tile through a register set requested two steps
-// ahead -- the bare data path 3-4 % faster, the whole kernel 1 % slower; and FIVE workgroups per CU -- one K buffer + a second, bare,
-// barrier, 27.6 KB of LDS, __launch_bounds__(256, 5) = 96 VGPRs with three spills outside the loop: 25 % more Q bytes in flight and a
-// fifth wave per SIMD, the launch 1 % slower.  Data path, issue and the power cap meet at this point.)
-#ifndef DAAM_TAP_EARLY_DMA
-#define DAAM_TAP_EARLY_DMA 1
-#endif
-// EIGHT waves per workgroup for the head_dim-64 launches (round 4: fp16 Q / K with fp16 sums, the headline; round 5: also bf16 Q / K and
-// f32 sums): 256 pixels of one head share ONE K tile.  Every
-// workgroup-step pulls its head's K tile (10 KB) out of L2 next to its Q rows (4 KB per wave); with 128-pixel workgroups that is 38 % of
-// what the CUs take in, and fetching it only every other step (-DDAAM_TAP_ABLATE=7, wrong results) made the launch 4 % shorter / +4.6 %
-// heat maps / s (LABNOTES R4.7).  Two workgroups of eight waves per CU = the same 4 waves per SIMD, 53 KB of LDS each.
-// -DDAAM_TAP_W8=0 (or DAAM_TAP_W8=0 in the environment) for A/B runs.
-#ifndef DAAM_TAP_W8
-#define DAAM_TAP_W8 1
-#endif
-
-// TLB-warming touch (experiment, off by default; -DDAAM_TAP_TOUCH=N): a wave reads ONE dword of the Q rows and of the K tensor it
-// will fetch N steps later.  Why: the launch time depends on the FOOTPRINT of the recorded Q / K, not only on the bytes moved
-// (tools/exp/pool_sweep.py: 1.65-1.67 ms with 1.2-4.7 GB of distinct step sets, 1.89-1.95 ms with 9.7-19.4 GB: the reach of
-// the address translation caches); every step of a deferred launch reads another tensor, i.e. other pages.
-#ifndef DAAM_TAP_TOUCH
-#define DAAM_TAP_TOUCH 0
-#endif
+// Data path of the head_dim-64 launches (FULL64: every SDXL / SD-2.x layer), as measured over rounds 1-5 (LABNOTES): K and Q go HBM -> LDS by
+// LDS-DMA (buffer_load ... lds: the swizzle is applied to the SOURCE address, the LDS image of a wave-instruction is lane-linear) instead of
+// through staging registers + ds_write_b128 (24 VGPRs fewer per lane-step); the next step's DMAs go out AHEAD of this step's MFMAs (K right
+// after the barrier, Q once the wave's four operand reads have returned); EIGHT waves per workgroup share ONE K tile (256 pixels of a head:
+// half the K traffic per pixel; two workgroups per CU = the same 4 waves per SIMD, 53 KB of LDS each).  head_dim < 64 (zero-padded chunks
+// cannot come from a DMA) takes the register-staged form on four waves.  The forms that were measured and dropped -- register-staged FULL64,
+// DMAs behind the MFMAs, four-wave FULL64, a second Q buffer two steps ahead, head-minor numbering, TLB touches, non-temporal Q, the timing
+// ablations -- live as patches under tools/exp/patches/ (tools/exp/build_variant.sh --lab), not in this file.
 
 namespace daam {
 
@@ -76,11 +43,10 @@ constexpr int kTapKBuf = kD64Rows * kTapRow;        // 10240: 80 K rows, rows 77
 constexpr int kTapQTile = 32 * kTapRow;             // 4096: one wave's 32 pixel rows
 constexpr int kTapQOff = 2 * kTapKBuf;              // Q tiles of the four waves follow the two K buffers
 
-// WAVES = waves per workgroup: 4 (128 pixels) or 8 (256 pixels of one head, ONE K tile for twice the pixels: see DAAM_TAP_W8)
-// Q2 (eight waves only): a second buffer for the FIRST half (16 rows) of every wave's Q tile -- see the kernel
-template <typename ACC_T, int WAVES = 4, bool Q2 = false> constexpr size_t tap_d64_lds_bytes() {
-    const size_t kb = 2 * (size_t)kTapKBuf + WAVES * (size_t)kTapQTile + (Q2 ? WAVES * (size_t)kTapQTile / 2 : 0), st = (size_t)kTok * (32 * WAVES) * sizeof(ACC_T);
-    return (kb > st ? kb : st) + (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*) + (DAAM_TAP_TOUCH ? 256 : 0);     // fp16 sums: 37888 -> 4 workgroups per CU
+// WAVES = waves per workgroup: 4 (128 pixels) or 8 (256 pixels of one head, ONE K tile for twice the pixels)
+template <typename ACC_T, int WAVES = 4> constexpr size_t tap_d64_lds_bytes() {
+    const size_t kb = 2 * (size_t)kTapKBuf + WAVES * (size_t)kTapQTile, st = (size_t)kTok * (32 * WAVES) * sizeof(ACC_T);
+    return (kb > st ? kb : st) + (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);     // fp16 sums: 37888 -> 4 workgroups per CU
 }
 
 // byte offset of 16-byte chunk `chunk` inside row `row` of a swizzled [rows][128 B] image
@@ -88,24 +54,16 @@ __device__ __forceinline__ constexpr int swz_chunk(int row, int chunk) { return 
 
 // FULL64: every layer of the launch has head_dim == 64 (SDXL): the zero-padding selects of the head_dim < 64 case (8 VALU per
 // wave-step) are compiled out
-// Q2 (round 5; WAVES == 8, DMA path): the two workgroups of a CU use 106 of its 160 KB of LDS, and what bounds the launch is its data
-// path -- ONE Q tile per wave in flight for ~0.9 of a step (LABNOTES R4.6).  With Q2 the first 16 pixel rows of a wave's tile have two
-// buffers and are requested TWO steps ahead (into the buffer whose operands were just read), the other 16 rows one step ahead as
-// before: 1.5 tiles in flight per wave at no VALU or register cost (LDS-DMA; round 4's register-set version paid for itself in
-// issue slots).  The step loop is unrolled by two so that the buffer of a step is an immediate offset.  69 KB of LDS, still two
-// workgroups per CU.
-template <typename IN, typename ACC_T, bool FAST_EXP, bool FULL64, int WAVES = 4, bool Q2 = false>
+template <typename IN, typename ACC_T, bool FAST_EXP, bool FULL64, int WAVES = 4>
 __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && !IN::kBf16)) ? 4 : 3)) void tap_d64_kernel(const TapLaunch L)
 {
-    static_assert(!Q2 || (WAVES == 8 && FULL64 && DAAM_TAP_DMA && DAAM_TAP_EARLY_DMA && !DAAM_TAP_TOUCH), "Q2: the eight-wave DMA form only");
     constexpr int NT = 64 * WAVES;                            // threads per workgroup
     constexpr int TILE = 32 * WAVES;                          // pixels per workgroup (the host sizes tiles_per_head with it)
-    static_assert(WAVES == 4 || (WAVES == 8 && FULL64 && DAAM_TAP_DMA), "eight waves: head_dim-64 launches on the DMA path only");
+    static_assert(WAVES == 4 || (WAVES == 8 && FULL64), "eight waves: head_dim-64 launches (the DMA path) only");
     constexpr int KCH = (kTok * 8 + 255) / 256;               // 16-B K pieces per thread per step (3)
     constexpr int VEC = AccVec<ACC_T>::kPerVec;
     constexpr int PPR = TILE / VEC;
-    constexpr size_t kPtrOff = tap_d64_lds_bytes<ACC_T, WAVES, Q2>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*) - (DAAM_TAP_TOUCH ? 256 : 0);
-    [[maybe_unused]] constexpr size_t kTouchOff = tap_d64_lds_bytes<ACC_T, WAVES, Q2>() - 256;     // DAAM_TAP_TOUCH: 256 bytes nobody reads
+    constexpr size_t kPtrOff = tap_d64_lds_bytes<ACC_T, WAVES>() - (size_t)kMaxStepsPerLaunch * 2 * sizeof(void*);
 
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* kbuf = smem;                               // [2][kTapKBuf], then the four waves' Q tiles
@@ -143,11 +101,7 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
     const int64_t k_off = b * lay.k_sb + hd * lay.k_sh;
     const int64_t q_off = b * lay.q_sb + hd * lay.q_sh;
 
-#if DAAM_TAP_DMA
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the DMA block choice must not become exec masks
-#else
-    const int lane = tid & 63, wave = tid >> 6;
-#endif
     const int j = lane & 15, h = lane >> 4;
 
     // ---- running sums -> registers (through the staging tile, 16-byte row pieces) --------------
@@ -225,7 +179,6 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
     for (int i = 0; i < 4; ++i) q_s[i] = 8 * i < q_rows_in ? (unsigned)i * q_step8 : 0u;
     // LDS write position of piece i: row (q_row + 8 i), swizzle key ((lane >> 4) + 4 i) & 7 = (lane >> 4) ^ 4 (i & 1)
     unsigned char* qtile = kbuf + kTapQOff + wave * kTapQTile;
-    [[maybe_unused]] unsigned char* qalt = kbuf + kTapQOff + WAVES * kTapQTile + wave * (kTapQTile / 2);   // Q2: second buffer of rows 0..15
     const int q_wr = q_row * kTapRow + ((q_chunk ^ (lane >> 4)) << 4);
     // operand reads: row l&15 of a 16-row tile, chunk 4 ks + (l >> 4); the same offset serves K (A) and Q (B)
     const int f_rd = j * kTapRow + swz_chunk(j, h);            // k-step 1: ^ 64
@@ -258,7 +211,7 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
     auto issue_q = [&](int s) {
         const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) qreg[i] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(qt, q_b0, q_s[i], DAAM_TAP_Q_AUX));
+        for (int i = 0; i < 4; ++i) qreg[i] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(qt, q_b0, q_s[i], 0));
     };
     auto commit_q = [&]() {
 #pragma unroll
@@ -268,7 +221,6 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
         }
     };
 
-#if DAAM_TAP_DMA
     // LDS-DMA form (FULL64 launches only).  K: 1 KiB block blk = WAVES j2 + wave (10 blocks: rows 8 blk .. 8 blk + 7; rows 77..79 re-read
     // row 76: finite, their logits are masked); lane -> row 8 blk + (lane >> 3), LDS chunk slot lane & 7 = source chunk
     // (lane & 7) ^ ((row >> 1) & 7).  Q: block i = rows 8 i .. 8 i + 7 of the wave's 32, same rule.
@@ -301,103 +253,37 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
         const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(qtile + i * 1024), 16, qd_src[i & 1], q_s[i], 0, DAAM_TAP_Q_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(qtile + i * 1024), 16, qd_src[i & 1], q_s[i], 0, 0);
     };
-    // Q2: rows 16..31 of step s (into the tile), rows 0..15 of step s (into buffer `alt`: the tile's first half or the second buffer)
-    [[maybe_unused]] auto dma_q_hi = [&](int s) {
-        const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
-#pragma unroll
-        for (int i = 2; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(qtile + i * 1024), 16, qd_src[i & 1], q_s[i], 0, DAAM_TAP_Q_AUX);
-    };
-    [[maybe_unused]] auto dma_q_lo = [&](int s, bool alt) {
-        const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)((alt ? qalt : qtile) + i * 1024), 16, qd_src[i & 1], q_s[i], 0, DAAM_TAP_Q_AUX);
-    };
-#endif
-#if DAAM_TAP_TOUCH
-    const unsigned q_touch = (unsigned)__builtin_amdgcn_readfirstlane(
-        (int)((q_off + (int64_t)min(p0 + wave * 32, lay.hw - 1) * lay.q_sp) * 2));
-#endif
     const floatx4 cmask = premask_tile4(h);
     // one denoising step: logits of step s from the K and Q tiles in LDS, then the fetches of the next step (head_dim 64: by DMA
     // into the other K buffer / this wave's own Q tile, whose reads are behind it; head_dim < 64: step s + 1 from the staging
     // registers into LDS and the request for step s + 2), softmax + accumulate of the two pixel groups
-    auto step = [&](int s, auto parity) {
-        [[maybe_unused]] constexpr bool kAlt = decltype(parity)::value;        // Q2: rows 0..15 of this step sit in the second buffer
-#if DAAM_TAP_TOUCH
-        // bare barrier: __syncthreads() carries a fence, for which hipcc waits vmcnt(0) -- the touches would be waited for after all.
-        // LDS visibility: this wave's DMAs were waited for at the end of the previous step, its LDS reads were consumed by the MFMAs
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#elif !defined(DAAM_TAP_ABLATE) || DAAM_TAP_ABLATE != 1       // timing experiment 1: no per-step barrier (results are wrong)
+    auto step = [&](int s) {
         __syncthreads();
-#endif
         const unsigned char* kb = kbuf + (s & 1) * kTapKBuf;
-#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 2            // timing experiment 2: every step re-reads step 0 (cache-resident)
-        [[maybe_unused]] const int s_fetch = 0;
-#else
         [[maybe_unused]] const int s_fetch = min(s + 1, n_steps - 1);   // branch-free: the last step re-fetches itself
-#endif
-#if DAAM_TAP_DMA && DAAM_TAP_EARLY_DMA
         // the K buffer of step s + 1 was last read in step s - 1 and every wave is past this step's barrier: its DMAs go out first
-#if defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 7            // timing experiment 7: the K tile only every other pair of steps (half the K traffic;
-        if constexpr (FULL64) { if (s & 2) dma_k(s_fetch, (s + 1) & 1); }   // results are wrong): the ceiling of sharing one K tile between more pixels
-#else
         if constexpr (FULL64) dma_k(s_fetch, (s + 1) & 1);
-#endif
-#endif
-        const unsigned char* qlo = (Q2 && kAlt) ? qalt : qtile;
-        const half8 q00 = *reinterpret_cast<const half8*>(qlo + f_rd), q01 = *reinterpret_cast<const half8*>(qlo + (f_rd ^ 64));
+        const half8 q00 = *reinterpret_cast<const half8*>(qtile + f_rd), q01 = *reinterpret_cast<const half8*>(qtile + (f_rd ^ 64));
         const half8 q10 = *reinterpret_cast<const half8*>(qtile + 16 * kTapRow + f_rd);
         const half8 q11 = *reinterpret_cast<const half8*>(qtile + 16 * kTapRow + (f_rd ^ 64));
-#if DAAM_TAP_DMA && DAAM_TAP_EARLY_DMA
         if constexpr (FULL64) {
             // this wave's Q tile is free once its four operand reads have returned: the next step's rows are requested BEFORE the MFMAs
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (Q2) {
-                dma_q_hi(s_fetch);                                  // one step ahead, as before
-                dma_q_lo(min(s + 2, n_steps - 1), kAlt);            // two steps ahead, into the buffer just read
-            } else {
-                dma_q(s_fetch);
-            }
+            dma_q(s_fetch);
         }
-#endif
         floatx4 c0[5], c1[5];
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
             const half8 a0 = *reinterpret_cast<const half8*>(kb + mt * 16 * kTapRow + f_rd);
             const half8 a1 = *reinterpret_cast<const half8*>(kb + mt * 16 * kTapRow + (f_rd ^ 64));
-#if defined(DAAM_TAP_ABLATE) && (DAAM_TAP_ABLATE == 3 || DAAM_TAP_ABLATE == 6)   // timing experiment 3: no MFMAs (and no operand reads); 6 = 3 + 5: the bare data path
-            c0[mt] = mt == 4 ? cmask : floatx4{(float)s, 1.f, 2.f, 3.f};
-            c1[mt] = mt == 4 ? cmask : floatx4{3.f, 2.f, 1.f, (float)s};
-            (void)a0; (void)a1; (void)q00; (void)q01; (void)q10; (void)q11;
-#else
             c0[mt] = IN::mfma(a0, q00, mt == 4 ? cmask : floatx4{0, 0, 0, 0});     // tokens 77..79: -inf from the start of their chain
             c1[mt] = IN::mfma(a0, q10, mt == 4 ? cmask : floatx4{0, 0, 0, 0});
             c0[mt] = IN::mfma(a1, q01, c0[mt]);
             c1[mt] = IN::mfma(a1, q11, c1[mt]);
-#endif
         }
-#if DAAM_TAP_DMA
-        if constexpr (FULL64) {
-            // the K buffer of step s + 1 was last read in step s - 1 (every wave is past this step's barrier); this wave's Q
-            // tile was read by the operand loads above, which the MFMAs have consumed
-#if !DAAM_TAP_EARLY_DMA
-            dma_k(s_fetch, (s + 1) & 1);
-            dma_q(s_fetch);
-#endif
-#if DAAM_TAP_TOUCH
-            {
-                // one dword of the Q rows / the K tensor this wave fetches DAAM_TAP_TOUCH steps later, by DMA into a scratch corner
-                // of LDS (never read): no destination registers, so nothing waits for them but the counted waits below
-                const int st = min(s + DAAM_TAP_TOUCH, n_steps - 1);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(tensor(sptr[2 * st]), (lds_ptr_t)(smem + kTouchOff), 4, 0, q_touch, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(tensor(sptr[2 * st + 1]), (lds_ptr_t)(smem + kTouchOff), 4, 0, k_base, 0, 0);
-            }
-#endif
-        } else {
+        if constexpr (!FULL64) {
             // head_dim < 64 (register-staged): the pieces of step s + 1 were requested a whole step ago -- into LDS now (K buffer
             // (s + 1) & 1 was last read in step s - 1, which every wave left before this step's barrier; the Q tile is this wave's
             // own and its operand reads are behind it), then the request for step s + 2 goes out: a fetch has a whole step to
@@ -407,24 +293,6 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
             issue_k(min(s + 2, n_steps - 1));                 // branch-free: the last steps re-fetch the last one
             issue_q(min(s + 2, n_steps - 1));
         }
-#elif defined(DAAM_TAP_ABLATE) && DAAM_TAP_ABLATE == 2           // timing experiment 2: every step re-reads step 0 (cache-resident)
-        issue_k(0);
-        issue_q(0);
-#else
-        issue_k(min(s + 1, n_steps - 1));                     // branch-free: the last step re-fetches itself
-        issue_q(min(s + 1, n_steps - 1));
-#endif
-#if defined(DAAM_TAP_ABLATE) && (DAAM_TAP_ABLATE == 5 || DAAM_TAP_ABLATE == 6)   // timing experiment 5: no softmax (the MFMA results are only folded into the sums)
-        if constexpr (sizeof(ACC_T) == 2 && !IN::kBf16) {
-#pragma unroll
-            for (int mt = 0; mt < 5; ++mt) {
-                run0[2 * mt] += __builtin_convertvector(float2v{c0[mt][0], c0[mt][1]}, half2v);
-                run0[2 * mt + 1] += __builtin_convertvector(float2v{c0[mt][2], c0[mt][3]}, half2v);
-                run1[2 * mt] += __builtin_convertvector(float2v{c1[mt][0], c1[mt][1]}, half2v);
-                run1[2 * mt + 1] += __builtin_convertvector(float2v{c1[mt][2], c1[mt][3]}, half2v);
-            }
-        } else
-#endif
         if constexpr (IN::kBf16) {
             softmax20_accumulate_bf16<ACC_T, true>(c0, lay, h, run0);
             softmax20_accumulate_bf16<ACC_T, true>(c1, lay, h, run1);
@@ -432,25 +300,12 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
             softmax20_accumulate<ACC_T, FAST_EXP, true>(c0, lay, h, run0);
             softmax20_accumulate<ACC_T, FAST_EXP, true>(c1, lay, h, run1);
         }
-#if DAAM_TAP_DMA
-        if constexpr (FULL64) {
-#if DAAM_TAP_TOUCH
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // the DMAs have landed; the two touches (issued last) may still be in flight
-#else
-            if constexpr (Q2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // all but the two newest (rows 0..15 of step s + 2) have landed
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs have landed; the next step's barrier publishes K
-#endif
-        }
-#else
-        commit_k((s + 1) & 1);
-        commit_q();
-#endif
+        // this wave's DMAs have landed; the next step's barrier publishes K
+        if constexpr (FULL64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-#if DAAM_TAP_DMA
     if constexpr (FULL64) {
         dma_k(0, 0);
         dma_q(0);
-        if constexpr (Q2) dma_q_lo(min(1, n_steps - 1), true);   // rows 0..15 of step 1 -> second buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         issue_k(0);
@@ -460,22 +315,7 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
         issue_k(min(1, n_steps - 1));
         issue_q(min(1, n_steps - 1));
     }
-#else
-    issue_k(0);
-    issue_q(0);
-    commit_k(0);
-    commit_q();
-#endif
-    if constexpr (Q2) {
-        int s = 0;
-        for (; s + 1 < n_steps; s += 2) {
-            step(s, std::false_type{});
-            step(s + 1, std::true_type{});
-        }
-        if (s < n_steps) step(s, std::false_type{});
-    } else {
-        for (int s = 0; s < n_steps; ++s) step(s, std::false_type{});
-    }
+    for (int s = 0; s < n_steps; ++s) step(s);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of the last (redundant) fetches is in flight any more
     __syncthreads();                                          // all K reads done before the staging tile reuses the space
 
@@ -508,35 +348,25 @@ bool tap_d64_supported(int head_dim, int hw, int64_t q_sp, int64_t k_st, int64_t
     return ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
 }
 
-template <typename IN, typename ACC_T, bool FAST, bool FULL64, int WAVES = 4, bool Q2 = false>
+template <typename IN, typename ACC_T, bool FAST, bool FULL64, int WAVES = 4>
 static hipError_t launch_d64_k(const TapLaunch& L, hipStream_t stream, int grid, size_t lds)
 {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_d64_kernel<IN, ACC_T, FAST, FULL64, WAVES, Q2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tap_d64_kernel<IN, ACC_T, FAST, FULL64, WAVES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((tap_d64_kernel<IN, ACC_T, FAST, FULL64, WAVES, Q2>), dim3(grid), dim3(64 * WAVES), lds, stream, L);
+    hipLaunchKernelGGL((tap_d64_kernel<IN, ACC_T, FAST, FULL64, WAVES>), dim3(grid), dim3(64 * WAVES), lds, stream, L);
     return hipGetLastError();
 }
 
 template <typename IN, typename ACC_T, bool FAST>
 static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, size_t* lds_out, bool full64, int waves8)
 {
-    constexpr bool kW8Build = (DAAM_TAP_W8 != 0) & (DAAM_TAP_DMA != 0);
-    if constexpr (kW8Build) {                                 // round 5: every dtype pair (bf16 Q / K and f32 sums fit 128 VGPRs at 119-128, no spills)
-        if constexpr (sizeof(ACC_T) == 2) {                     // (f32 sums: the loop unrolled by two spills at 128 VGPRs -- they keep one step ahead)
-            if (waves8 == 2 && full64) {                        // Q2: rows 0..15 of the Q tiles two steps ahead
-                const size_t lds8 = tap_d64_lds_bytes<ACC_T, 8, true>();
-                *lds_out = lds8;
-                return launch_d64_k<IN, ACC_T, FAST, true, 8, true>(L, stream, grid, lds8);
-            }
-        }
-        if (waves8 && full64) {
-            const size_t lds8 = tap_d64_lds_bytes<ACC_T, 8>();
-            *lds_out = lds8;
-            return launch_d64_k<IN, ACC_T, FAST, true, 8>(L, stream, grid, lds8);
-        }
+    if (waves8 && full64) {                                   // every dtype pair fits 128 VGPRs (101-128), no spills
+        const size_t lds8 = tap_d64_lds_bytes<ACC_T, 8>();
+        *lds_out = lds8;
+        return launch_d64_k<IN, ACC_T, FAST, true, 8>(L, stream, grid, lds8);
     }
     if (waves8) return hipErrorInvalidValue;                  // the host sized the tiles for eight waves: no other form may run them
     const size_t lds = tap_d64_lds_bytes<ACC_T>();
@@ -548,9 +378,8 @@ static hipError_t launch_d64(const TapLaunch& L, hipStream_t stream, int grid, s
 // with fp16 or f32 sums, bf16 Q / K with bf16 or f32 sums), else 128
 int tap_d64_tile_pixels(int in_dtype, int acc_dtype, int full64)
 {
-    constexpr bool kW8Build = (DAAM_TAP_W8 != 0) & (DAAM_TAP_DMA != 0);
     const bool pair = (in_dtype == 0 && (acc_dtype == 0 || acc_dtype == 1)) || (in_dtype == 2 && (acc_dtype == 2 || acc_dtype == 1));
-    return (kW8Build && pair && full64) ? 256 : 128;
+    return (pair && full64) ? 256 : 128;
 }
 
 hipError_t launch_tap_d64(const TapLaunch& L, int in_dtype, int acc_dtype, int fast_exp, int full64, int waves8, hipStream_t stream, int* grid_out, int* lds_out)

@@ -22,12 +22,7 @@
 
 namespace daam {
 
-#if defined(DAAM_ABLATE) && DAAM_ABLATE == 9
-__device__ unsigned long long daam_dbg[1024][8];
-#define DAAM_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[i] += t_ - t_prev; t_prev = t_; } while (0)
-#else
 #define DAAM_T(i) do {} while (0)
-#endif
 
 template <int KS, typename ACC_T>
 constexpr size_t tap_mfma_lds_bytes() {
@@ -37,11 +32,8 @@ constexpr size_t tap_mfma_lds_bytes() {
 }
 
 // waves per SIMD the register allocator must leave room for: 4 for the fp16-sum SD/SDXL head dims
-#ifndef DAAM_FAST_WAVES
-#define DAAM_FAST_WAVES 3
-#endif
 template <int KS, typename ACC_T, bool FAST> constexpr int tap_mfma_min_waves() {
-    return (KS <= 4 && sizeof(ACC_T) == 2) ? (FAST ? DAAM_FAST_WAVES : 4) : 2;
+    return (KS <= 4 && sizeof(ACC_T) == 2) ? (FAST ? 3 : 4) : 2;
 }
 
 template <int KS, typename ACC_T, bool FAST_EXP>
@@ -164,10 +156,6 @@ __global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T, FAST_EXP>())) v
     issue_k(0);
     issue_q(0);
     commit_k(0);
-#if defined(DAAM_ABLATE) && DAAM_ABLATE == 9
-    unsigned long long t_acc[4] = {0, 0, 0, 0};
-    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
-#endif
     for (int s = 0; s < n_steps; ++s) {
         DAAM_T(0);                                            // commit_k + loop overhead of the previous step
         __syncthreads();
@@ -195,10 +183,6 @@ __global__ __launch_bounds__(256, (tap_mfma_min_waves<KS, ACC_T, FAST_EXP>())) v
         DAAM_T(3);                                            // load issue + softmax + accumulate
         commit_k((s + 1) & 1);
     }
-#if defined(DAAM_ABLATE) && DAAM_ABLATE == 9
-    if (lane == 0 && wave == 0 && wg < 1024)
-        for (int i = 0; i < 4; ++i) daam_dbg[wg][i] += t_acc[i];
-#endif
     __syncthreads();                                          // all K reads done before the staging tile reuses the space
 
     // ---- write back: registers -> LDS [token][pixel] -> 16-byte row pieces -------------------
@@ -229,11 +213,6 @@ bool tap_mfma_supported(int in_dtype, int head_dim, int tokens, int hw, int64_t 
     return true;
 }
 
-#if defined(DAAM_ABLATE) && DAAM_ABLATE == 9
-extern "C" __attribute__((visibility("default"))) int daam_debug_dump(unsigned long long* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(daam_dbg), sizeof(unsigned long long) * 1024 * 8);
-}
-#endif
 int tap_mfma_tile_pixels() { return kMfmaPixels; }
 int tap_mfma_max_steps() { return kMaxStepsPerLaunch; }
 int tap_mfma_ksteps(int head_dim) { return (head_dim + 15) / 16; }

@@ -33,22 +33,10 @@
 //   softmax + accumulate (running sums stay in registers for the whole launch)
 #include "daam_tap16_softmax.h"
 
-// Debug aid (tools/exp/slab_timeline.py; build with -DDAAM_SLAB_TIMING): per-workgroup stamps -- 100 MHz reference counter at the start, at
-// the first step, after the last step and at the end; shader cycles wave 0 spent waiting at the head of the steps (DMA wait + barrier) and
-// in the whole loop; head_dim; HW_ID.
-// cache policy of the Q fetches (every Q line is read exactly once per launch, by one workgroup): 2 = non-temporal (default), 0 = the default
-// policy (A/B: -DDAAM_SLAB_Q_AUX=0).  SD-v1.5, alternating three times on one box: 2517 / 2517 / 2515 -> 2583 / 2589 / 2579 maps/s, tap 0.351 ->
-// 0.342 ms with nt (the once-read Q lines no longer push the K slabs, which every tile of a layer re-reads, out of the L2s).  The same switch
-// on the head_dim-64 kernel (-DDAAM_TAP_Q_AUX=2) is neutral on the headline (its K tiles are 5x smaller per byte of Q).
-#ifndef DAAM_SLAB_Q_AUX
-#define DAAM_SLAB_Q_AUX 2
-#endif
-#ifdef DAAM_SLAB_TIMING
-__device__ unsigned long long daam_slab_dbg[4096][8];
-#define DAAM_ST(i, v) do { if (threadIdx.x == 0 && wg < 4096) daam_slab_dbg[wg][i] = (v); } while (0)
-#else
-#define DAAM_ST(i, v) do {} while (0)
-#endif
+// Cache policy of the Q fetches: non-temporal (2).  Every Q line is read exactly once per launch, by one workgroup; with nt the once-read
+// lines no longer push the K slabs, which every tile of a layer re-reads, out of the L2s: SD-v1.5 2517 -> 2583 maps/s, tap 0.351 -> 0.342 ms,
+// alternating three times on one box (LABNOTES R5.9; neutral on the head_dim-64 kernel, whose K tiles are 5x smaller per byte of Q).
+constexpr int kSlabQAux = 2;
 
 namespace daam {
 
@@ -204,10 +192,10 @@ __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& 
     };
     auto dma_q = [&](int s) {                                 // two instructions (waves 0..3: three)
         const __amdgpu_buffer_rsrc_t qt = tensor(sptr[2 * s]);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + kSlabQOff + wave * 1024), 16, qdA, q_base, 0, DAAM_SLAB_Q_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + kSlabQOff + wave * 1024), 16, qdA, q_base, 0, kSlabQAux);
         if constexpr (TP == kSlabPx)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + kSlabQOff + (wave + 10) * 1024), 16, qdA, q_base + q16, 0, DAAM_SLAB_Q_AUX);
-        if (wave < TP / 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + xq_lds), 16, xd, xq_s, 0, DAAM_SLAB_Q_AUX);   // 16-pixel tiles: instructions 8, 9 only
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + kSlabQOff + (wave + 10) * 1024), 16, qdA, q_base + q16, 0, kSlabQAux);
+        if (wave < TP / 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(qt, (lds_ptr_t)(smem + xq_lds), 16, xd, xq_s, 0, kSlabQAux);   // 16-pixel tiles: instructions 8, 9 only
     };
 
     // ---- operand reads: lane (j, h) of k-step ks takes piece 4 ks + h of its head from row j of a 16-row tile; the same offset
@@ -227,21 +215,9 @@ __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& 
     const floatx4 cmask = premask_tile4(h);
     dma_k(0);
     dma_q(0);
-#ifdef DAAM_SLAB_TIMING
-    unsigned long long waited = 0, waited3 = 0, w0 = 0;
-    const unsigned long long loop0 = __builtin_amdgcn_s_memtime();
-    DAAM_ST(1, __builtin_amdgcn_s_memrealtime());
-#define DAAM_SW0() w0 = __builtin_amdgcn_s_memtime()
-#define DAAM_SW1(acc) acc += __builtin_amdgcn_s_memtime() - w0
-#else
-#define DAAM_SW0() do {} while (0)
-#define DAAM_SW1(acc) do {} while (0)
-#endif
     for (int s = 0; s < n_steps; ++s) {
         const int s_next = min(s + 1, n_steps - 1);           // branch-free: the last step re-fetches itself
-        DAAM_SW0();
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");          // every wave's part of K(s) and Q(s) has landed
-        DAAM_SW1(waited);
         half8 qv[G][NKS];
         if (active) {
 #pragma unroll
@@ -265,27 +241,13 @@ __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& 
                         c[g][mt] = InF16::mfma(a, qv[g][ks], ks == 0 ? (mt == 4 ? cmask : floatx4{0, 0, 0, 0}) : c[g][mt]);   // tokens 77..79: -inf from the start
                 }
         }
-        DAAM_SW0();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // the K slab has been read by everyone
-        DAAM_SW1(waited3);
         dma_k(s_next);
         if (active) {
             softmax20_accumulate<ACC_T, FAST_EXP, true>(c[0], lay, h, run0);
             if constexpr (G == 2) softmax20_accumulate<ACC_T, FAST_EXP, true>(c[G - 1], lay, h, run1);
         }
     }
-#ifdef DAAM_SLAB_TIMING
-    DAAM_ST(2, __builtin_amdgcn_s_memrealtime());
-    DAAM_ST(4, waited | (waited3 << 32));
-    DAAM_ST(5, __builtin_amdgcn_s_memtime() - loop0);
-    DAAM_ST(6, (unsigned long long)D | ((unsigned long long)n_steps << 16));
-    {
-        unsigned hw_id, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        DAAM_ST(7, (unsigned long long)hw_id | ((unsigned long long)xcc << 32));
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");              // nothing of the last (redundant) fetches is in flight: LDS is free
 
     // ---- write back: registers -> wave-private [token][pixel] tile -> 16-byte row pieces -------------------------------------
@@ -304,7 +266,6 @@ __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& 
                 *as_global_rw<float4v>(acc + (size_t)row * lay.hw + px0 + col) = *reinterpret_cast<const float4v*>(stage + row * TW + col);
         }
     }
-    DAAM_ST(3, __builtin_amdgcn_s_memrealtime());
 }
 
 template <typename ACC_T, bool FAST_EXP>
@@ -313,7 +274,6 @@ __global__ __launch_bounds__(64 * kSlabWaves, 4) void tap_slab_kernel(const TapL
     extern __shared__ __align__(16) unsigned char smem[];
     const int wg = slab_logical_block(L);
     if (wg < 0) return;
-    DAAM_ST(0, __builtin_amdgcn_s_memrealtime());
     tap_mark_started(L);
     TapLayer lay;
     const DAAM_GLOBAL TapLayer* gl = as_global<TapLayer>(L.layers);
@@ -385,8 +345,3 @@ hipError_t launch_tap_slab(const TapLaunch& L, int acc_dtype, int fast_exp, hipS
 
 }  // namespace daam
 
-#ifdef DAAM_SLAB_TIMING
-extern "C" __attribute__((visibility("default"))) int daam_debug_dump_slab(unsigned long long* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(daam_slab_dbg), sizeof(daam_slab_dbg));
-}
-#endif

@@ -17,13 +17,25 @@ COMMON = ['--steps', '3', '--warmup', '1', '--no-baselines', '--no-integrated', 
 
 
 def _bench(*extra, timeout=600, **env_extra):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **env_extra)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *COMMON, *extra], env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, text=True, timeout=timeout)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, p.stdout[-2000:]                   # rank 0 prints, nobody else does
-    return json.loads(lines[0])
+    """Runs bench.py; returns the parsed headline line (what the driver records: one strict-JSON line < 4 KB on stdout) with the
+    full record (the file the line names) under ``['_full']``."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        full_path = os.path.join(tmp, 'bench_full.json')
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', BENCH_FULL_RECORD=full_path, **env_extra)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *COMMON, *extra], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=timeout)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+        assert len(lines) == 1 and p.stdout.strip() == lines[0], p.stdout[-2000:]   # rank 0 prints ONE line, nobody else prints anything
+        assert len(lines[0].encode()) < 4096, len(lines[0])
+
+        def no_constant(name):
+            raise ValueError(f'non-strict JSON constant {name}')
+        rec = json.loads(lines[0], parse_constant=no_constant)
+        assert rec['full_record'] == full_path
+        rec['_full'] = json.load(open(full_path))
+    return rec
 
 
 def test_bench_two_ranks_one_device():
@@ -38,8 +50,9 @@ def test_bench_two_ranks_one_device():
     # the single-rank line measured its HBM traffic in the run (two children under rocprofv3 --pmc)
     # (a box without the profiler / without PMC access: bench.py degrades to the committed counters and says why -- not a failure)
     import shutil
-    if shutil.which('rocprofv3') is None or one['roofline'].get('traffic_in_run_note'):
-        assert one['roofline']['traffic_measured_in_run'] is False and one['roofline'].get('traffic_in_run_note'), one['roofline']
+    full_ro = one['_full']['roofline']
+    if shutil.which('rocprofv3') is None or full_ro.get('traffic_in_run_note'):
+        assert one['roofline']['traffic_measured_in_run'] is False and full_ro.get('traffic_in_run_note'), full_ro
     else:
         assert one['roofline']['traffic_measured_in_run'] is True, one['roofline']
         assert 0.9 <= one['roofline']['traffic_over_algorithmic'] <= 1.3, one['roofline']
@@ -50,9 +63,15 @@ def test_bench_two_ranks_one_device():
     assert 0.3 * one["value"] <= two["value"] <= 1.5 * one["value"], (one['value'], two['value'])
     assert two['roofline']['launches_per_generation'] == 1 and two['roofline']['frac'] > 0.1
     # the single-rank line carries the sustained-state figure next to the (short) timed region; multi-rank lines do not
-    assert one['sustained']['seconds'] >= 2.0 and one['sustained_maps_per_s'] > 0 and one['sustained_tap_ms'] > 0, one.get('sustained')
-    assert 'sustained' not in two
-    assert two['config']['rank_cpu_affinity'] is None or 'cores' in two['config']['rank_cpu_affinity']
+    assert one['_full']['sustained']['seconds'] >= 2.0 and one['sustained_maps_per_s'] > 0 and one['sustained_tap_ms'] > 0, one['_full'].get('sustained')
+    assert 'sustained' not in two['_full'] and 'sustained_maps_per_s' not in two
+    aff = two['_full']['config']['rank_cpu_affinity']
+    assert aff is None or 'cores' in aff
+    # the line is the contract's fields + roofline + cpu_baseline + scalars; the detail lives in the full record
+    for rec in (one, two):
+        assert all(not isinstance(v, (dict, list)) for k, v in rec.items() if k not in ('config', 'roofline', 'cpu_baseline', '_full'))
+        assert rec['_full']['value'] == rec['value'] and 'roofline_issue' in rec['_full'] and 'roofline_issue' not in rec
+    assert one['warmup'] == 1 and one['warmup_effective'] >= 20
 
 
 def test_bench_two_ranks_without_the_launcher_module():

@@ -815,8 +815,7 @@ def test_full_size_layer_properties(heads, side, d):
 def test_eight_wave_partial_tiles_50_deferred_steps_vs_oracle(side, mode, monkeypatch):
     """The eight-wave head_dim-64 form (256-pixel tiles; round 5: for bf16 / f32 sums as well) on layers whose last tile is PARTIAL --
     hw = 576 (SD-2.x at 768 px: 2.25 tiles) and 2304 (9 tiles) -- through a 50-step deferred launch, against the numpy oracle; and
-    bit-identical to the form that requests half of every Q tile two steps ahead (DAAM_TAP_Q2=1, opt-in) and to the four-wave form
-    (DAAM_TAP_W8=0).  Reference: daam/trace.py:233,240 (unravel), heatmap.py:153-156 (the running sum)."""
+    bit-identical to the four-wave form (DAAM_TAP_W8=0).  Reference: daam/trace.py:233,240 (unravel), heatmap.py:153-156 (the running sum)."""
     import ctypes
     from daam_amd import _native as nat
     from daam_amd import engine as E
@@ -828,9 +827,9 @@ def test_eight_wave_partial_tiles_50_deferred_steps_vs_oracle(side, mode, monkey
     qs, ks = zip(*[_qk(rng, 2, heads, hw, d, np_dt) for _ in range(steps)])
     want = _oracle_steps(qs, ks, heads, scale, np_dt, acc_np).astype(np.float64)
     got = {}
-    for tag, env in (('default', {}), ('two_steps_ahead', dict(DAAM_TAP_Q2='1')), ('four_waves', dict(DAAM_TAP_W8='0'))):
+    for tag, env in (('default', {}), ('four_waves', dict(DAAM_TAP_W8='0'))):
         E.release_parked_contexts()                          # the switches are read when a native context is created
-        for var in ('DAAM_TAP_Q2', 'DAAM_TAP_W8'):
+        for var in ('DAAM_TAP_W8',):
             monkeypatch.delenv(var, raising=False)
         for var, val in env.items():
             monkeypatch.setenv(var, val)
@@ -844,11 +843,10 @@ def test_eight_wave_partial_tiles_50_deferred_steps_vs_oracle(side, mode, monkey
         assert block.value == (256 if tag == 'four_waves' else 512), (tag, block.value)
         if tag != 'four_waves':
             assert grid.value >= heads * -(-hw // 256)       # 256-pixel tiles: 3 / 9 per head (the grid is rounded up to 8 XCDs)
-            two_ahead = tag == 'two_steps_ahead' and not mode.endswith('_f32acc')
-            assert (lds.value >= 69 * 1024) == (two_ahead or mode.endswith('_f32acc')), (tag, lds.value)
+            assert (lds.value >= 69 * 1024) == mode.endswith('_f32acc'), (tag, lds.value)
         eng.close()
     E.release_parked_contexts()
-    assert torch.equal(got['default'], got['two_steps_ahead']) and torch.equal(got['default'], got['four_waves'])
+    assert torch.equal(got['default'], got['four_waves'])
     g = got['default'].numpy().astype(np.float64)
     assert g.shape == want.shape
     # tolerance of the 50-step full-size tests (tests/test_gpu_integration.py): the implementations round at the same points but sum

@@ -682,11 +682,11 @@ def test_generation_experiment_round_trip(tmp_path):
 
 
 def test_generated_finalize_schedule_is_current(tmp_path):
-    """daam_amd/csrc/daam_finalize_pipe_{prefill,asm}_r{8,16}.inc are generated (tools/gen_fin_pipe.py): the committed files must
-    be what the generator writes today, for both ring depths."""
+    """daam_amd/csrc/daam_finalize_pipe_{prefill,asm}_r16.inc are generated (tools/gen_fin_pipe.py): the committed files must
+    be what the generator writes today."""
     import subprocess
     import sys
-    for ring in ('8', '16'):
+    for ring in ('16',):
         env = dict(os.environ, DAAM_PIPE_RING=ring, DAAM_PIPE_OUTDIR=str(tmp_path))
         for k in ('DAAM_PIPE_ABLATE', 'DAAM_PIPE_SCHED', 'DAAM_PIPE_NT', 'DAAM_PIPE_OUT'):
             env.pop(k, None)
