@@ -254,10 +254,9 @@ struct DaamCtx {
     unsigned* gate_timeouts = nullptr; // pinned, device-mapped: gates that gave up after their 200 us (the side kernels were NOT running beside them)
     unsigned* gate_timeouts_dev = nullptr;
     int no_start_gate = 0;             // DAAM_NO_START_GATE=1 (debugging / A-B), or a failed flush left counter and target in disagreement
-    unsigned gate_timeouts_seen = 0;   // value of *gate_timeouts when the previous gated flush was enqueued
-    int gate_strikes = 0;              // consecutive gated flushes whose gate timed out
+    unsigned gate_timeouts_seen = 0;   // value of *gate_timeouts when the gate was last armed
+    unsigned long long gate_enqueued = 0;   // gated flushes enqueued since then
     long long gate_off_until = 0;      // n_flushes at which a gate that was dropped for timing out is tried again (0 = in use)
-    bool gate_prev_gated = false;      // the previous multi-kernel flush carried a gate
     bool gate_said = false;
     int no_side_stream = 0;
 
@@ -999,7 +998,9 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         // step chains), 40 (the bulk), 80 (short chains), and last the TAIL of the head_dim-40 layers in half-size workgroups: 2.2 rounds of
         // indivisible 50-step chains leave a third of the chip idle for the last 100 us of the launch; half-length units empty it more evenly
         // (DAAM_SLAB_TAIL = percent of a head_dim-40 layer's pixels that go there; bit-identical sums either way).  Every XCD takes an eighth of
-        // each segment.
+        // each segment.  Round 6 searched the order with a list-scheduling model (tools/slab_order_model.py) and measured its best candidate
+        // ("columns": first halves heavy-first, second halves light-first, half-size units last) on the chip: 3 % SLOWER than this order for
+        // every tail share (LABNOTES R6.2) -- a chain's speed depends on what shares its CU, which the model does not know.
         auto seg_rank = [](int d) { return d == 160 ? 0 : d == 40 ? 1 : 2; };
         for (size_t i = 0; i < order.size(); ++i) {
             if (kind[i] != kd) continue;
@@ -1026,7 +1027,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
             for (auto* p : per[i]) { hp[ptr].q = p->q; hp[ptr].k = p->k; ++ptr; }
         }
         size_t j = 0;
-        int seg_begin[5] = {0, 0, 0, 0, 0}, n_seg = 0;
+        int seg_begin[kMaxSlabSegs + 1] = {0}, n_seg = 0;
         int last_rank = -1;
         for (const Ent& en : ents) {
             const auto& v = per[en.i];
@@ -1069,8 +1070,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
         pr.L.total_wgs = wg;
         pr.L.wgs_per_xcd = (wg + 7) / 8;
         pr.L.n_seg = n_seg;
-        for (int k = 0; k < 5; ++k) pr.L.seg_begin[k] = seg_begin[k];
-        pr.L.head_minor = 0;
+        for (int k = 0; k <= kMaxSlabSegs; ++k) pr.L.seg_begin[k] = seg_begin[k];
         pr.max_d = max_d;
         pr.min_d = min_d;
         pr.all_round = all_round;
@@ -1105,24 +1105,24 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     if (forked) launch_order.push_back(main_idx);
     int n_side = 0;
     // start gate: the side kernels' workgroups count themselves in, the main kernel waits (one wave, bounded) until they are
-    // resident -- only for the kernels that carry the counter (the MFMA kinds)
-    // a gate of an earlier flush ran into its timeout: the auxiliary streams do not run beside the caller's here (one hardware queue,
-    // GPU_MAX_HW_QUEUES) -- every gated flush would pay the 200 us for nothing, so the context stops using it (said once)
+    // resident -- only for the kernels that carry the counter (the MFMA kinds).
     // A gate that runs into its 200 us timeout means the side kernels were NOT running beside the caller's stream at that moment (one
-    // hardware queue, GPU_MAX_HW_QUEUES; or another process held the GPU).  One such delay must not cost the context its gate for good:
-    // it is dropped after three CONSECUTIVE gated flushes that timed out, said once, and tried again 64 flushes later.
+    // hardware queue, GPU_MAX_HW_QUEUES; or another process held the GPU): every gated flush then pays the 200 us for nothing.  The
+    // timeout counter is pinned host memory the gate kernels bump; the host reads it here WITHOUT synchronising, so it lags the
+    // enqueued flushes by however many are still in flight.  Rule (robust against that lag): since the gate was last armed, at least
+    // three timeouts AND at least half of the gated flushes enqueued so far timed out -> the gate rests for 64 flushes (said once),
+    // then is armed again with fresh counts.
     if (forked && c->gate_timeouts) {
         const unsigned now = *reinterpret_cast<volatile unsigned*>(c->gate_timeouts);
-        if (c->gate_off_until && c->n_flushes >= c->gate_off_until) { c->gate_off_until = 0; c->gate_strikes = 0; c->gate_timeouts_seen = now; }
-        if (!c->gate_off_until && c->gate_prev_gated) {
-            c->gate_strikes = now != c->gate_timeouts_seen ? c->gate_strikes + 1 : 0;
-            c->gate_timeouts_seen = now;
-            if (c->gate_strikes >= 3) {
+        if (c->gate_off_until && c->n_flushes >= c->gate_off_until) { c->gate_off_until = 0; c->gate_timeouts_seen = now; c->gate_enqueued = 0; }
+        if (!c->gate_off_until) {
+            const unsigned timeouts = now - c->gate_timeouts_seen;         // since armed (unsigned wrap-around is fine)
+            if (timeouts >= 3 && 2 * (unsigned long long)timeouts >= c->gate_enqueued) {
                 c->gate_off_until = c->n_flushes + 64;
                 if (!c->gate_said) {
                     c->gate_said = true;
-                    fprintf(stderr, "libdaam_hip: the start gate of three multi-kernel tap launches in a row timed out (side streams not concurrent with "
-                                    "the caller's stream); the gate rests for 64 launches\n");
+                    fprintf(stderr, "libdaam_hip: the start gate of %u of %llu multi-kernel tap launches timed out (side streams not concurrent with "
+                                    "the caller's stream); the gate rests for 64 launches\n", timeouts, c->gate_enqueued);
                 }
             }
         }
@@ -1167,7 +1167,7 @@ int daam_tap_flush(DaamCtx* c, void* stream)
     // a flush that failed part-way may have announced side workgroups that never started: counter and target would disagree for
     // good (every later gate a silent no-op or a full timeout), so the context stops gating
     if (rc && gate) c->no_start_gate = 1;
-    if (forked) c->gate_prev_gated = gate && gate_wgs != 0;
+    if (forked && gate && gate_wgs != 0) ++c->gate_enqueued;
     // join (after the main kernel is enqueued): the caller's stream continues when every side kernel is done
     for (int i = 0; i < n_side; ++i)
         if (hipStreamWaitEvent(s, c->aux_join[i], 0) != hipSuccess) rc = rc ? rc : fail(DAAM_E_STATE, "stream join failed");

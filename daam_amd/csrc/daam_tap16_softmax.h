@@ -7,6 +7,13 @@ namespace daam {
 
 // softmax over the 77 tokens of the lane's pixel (20 slots here, 57 in the three partner lanes)
 // + accumulate.  c[mt][r] = f32 q.k of token 16mt + 4h + r.
+// a POSITIVE, normal power of two (attention scales are: head_dim^-1/2 of 64, 16, 256): only then may the scale be folded into the exponent
+// constant / the logits stay unscaled in the overflow redo (a negative, zero, inf or NaN "scale" takes the general branch, which handles any sign)
+__device__ __forceinline__ bool scale_is_pow2(float scale) {
+    const unsigned b = __float_as_uint(scale);
+    return (b & 0x807fffffu) == 0 && b != 0 && b < 0x7f800000u;
+}
+
 template <typename ACC_T> struct Pair;
 template <> struct Pair<_Float16> { using T = half2v; };
 template <> struct Pair<float> { using T = float2v; };
@@ -80,7 +87,7 @@ __device__ __forceinline__ void softmax20_probs_bf16(const floatx4 (&c)[5], floa
     // result is a bf16 subnormal), so the logits stay unscaled and the scale is folded into L -- as in the fp16 path; 10 packed
     // multiplies fewer per 16 pixels (round 5).  The conversion is the COMPILER's v_cvt_pk_bf16_f32 there (not the asm helper): it is the
     // first VALU read of the MFMA results, and only instructions the compiler can see get their MFMA -> VALU wait states padded.
-    const bool pow2 = (__float_as_uint(scale) & 0x007fffffu) == 0;         // wave-uniform
+    const bool pow2 = scale_is_pow2(scale);                                // wave-uniform
     float2v x[kSlots16 / 2];
     if (pow2) {
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -161,7 +168,7 @@ __device__ __forceinline__ void softmax20_accumulate_bf16(const floatx4 (&c)[5],
 template <bool PREMASKED>
 __device__ __forceinline__ void softmax20_probs_fast(const floatx4 (&c)[5], float scale, int h, half2v (&ph)[kSlots16 / 2])
 {
-    const bool pow2 = (__float_as_uint(scale) & 0x007fffffu) == 0;          // wave-uniform
+    const bool pow2 = scale_is_pow2(scale);                                // wave-uniform
     half2v xh[kSlots16 / 2];
     if (pow2) {
         // compiler-generated v_cvt_pk_f16_f32 (not the asm helper): this is the first VALU read of the MFMA results,

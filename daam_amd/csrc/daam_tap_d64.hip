@@ -94,8 +94,8 @@ __global__ __launch_bounds__(64 * WAVES, ((WAVES == 8 || (sizeof(ACC_T) == 2 && 
     }
     const int n_steps = lay.n_steps;
     const int rel = wg - lay.wg_begin;
-    const int kh = L.head_minor ? rel % lay.heads_kept : rel / lay.tiles_per_head;
-    const int p0 = (L.head_minor ? rel / lay.heads_kept : rel - kh * lay.tiles_per_head) * TILE;
+    const int kh = rel / lay.tiles_per_head;                  // (head, tile) numbering: the tiles of a head share its K tile out of one L2
+    const int p0 = (rel - kh * lay.tiles_per_head) * TILE;
     const int bh = lay.bh_first + kh;
     const int b = bh / lay.heads, hd = bh - b * lay.heads;
     const int64_t k_off = b * lay.k_sb + hd * lay.k_sh;

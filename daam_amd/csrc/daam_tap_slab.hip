@@ -205,6 +205,9 @@ __device__ __forceinline__ void slab_body(unsigned char* smem, const TapLaunch& 
     for (int ks = 0; ks < NKS; ++ks) {
         const int pi = 4 * ks + h;
         const bool valid = pi < PPH;
+        // (lanes past the head's last piece in the tail k-step: K from a valid piece of the same head x the ZERO piece of Q = 0 for finite K.
+        // The chunked / wide kernels zero-pad K instead; the two differ only when that K piece holds inf / NaN (0 x inf = NaN here) -- inputs for
+        // which the reference's softmax yields NaN rows for the head as well)
         const int p = head * PPH + (valid ? pi : 4 * ks);
         f_k[ks] = (unsigned)(j * kSlabBytes + ((p ^ ((j >> 1) & 7)) << 4));
         f_q[ks] = valid ? (unsigned)(kSlabQOff + 16 * grp * kSlabBytes) + f_k[ks] : (unsigned)kSlabZeroOff;
@@ -322,7 +325,7 @@ static hipError_t launch_slab_k(const TapLaunch& L, hipStream_t stream, int grid
 // L.seg_begin / L.n_seg describe the segments (see slab_logical_block); acc_dtype 0 = fp16, 1 = f32 sums
 hipError_t launch_tap_slab(const TapLaunch& L, int acc_dtype, int fast_exp, hipStream_t stream, int* grid_out, int* lds_out)
 {
-    if (L.n_seg < 1 || L.n_seg > 4 || !L.layers) return hipErrorInvalidValue;
+    if (L.n_seg < 1 || L.n_seg > kMaxSlabSegs || !L.layers) return hipErrorInvalidValue;
     int per = 0;                                              // workgroups of the fullest XCD
     for (int x = 0; x < 8; ++x) {
         int n_x = 0;

@@ -20,6 +20,7 @@ template <typename T> __device__ __forceinline__ DAAM_GLOBAL T* as_global_rw(voi
 
 constexpr int kMaxTokens = 80;        // context_size is 77 (reference trace.py:194); padded tiles use 80 / 96
 constexpr int kTapPixels = 64;        // query positions per workgroup tile (generic kernel)
+constexpr int kMaxSlabSegs = 4;      // segments of a tap_slab_kernel launch (TapLaunch::seg_begin)
 constexpr int kTapParts = 4;          // token chunks per pixel (one per wave of the 256-thread block)
 constexpr int kTokPerPart = kMaxTokens / kTapParts;   // 20
 
@@ -64,13 +65,10 @@ struct TapLaunch {
                             // flush (daam_tap_flush) holds the large kernel back until the small ones' workgroups are resident
     TapLayer one;
     TapPtr one_ptr;
-    // tap_slab_kernel (daam_tap_slab.hip): the launch's workgroups are listed segment by segment -- [seg_begin[k], seg_begin[k + 1]) = the
-    // layers of one head_dim -- and every XCD takes an eighth of each segment
+    // tap_slab_kernel (daam_tap_slab.hip): the launch's workgroups are listed segment by segment -- [seg_begin[k], seg_begin[k + 1]) = table
+    // entries of one cost (a head_dim's layers, or a pixel range of them) -- and every XCD takes an eighth of each segment, in order
     int32_t n_seg;
-    int32_t seg_begin[5];
-    // tap_d64_kernel: 1 = a layer's workgroups are numbered head-minor (tile, head) instead of (head, tile): the workgroups that run side by
-    // side on an XCD then read ADJACENT heads of the same pixel rows -- contiguous 128-byte pieces of the same DRAM pages (DAAM_TAP_HEAD_MINOR)
-    int32_t head_minor;
+    int32_t seg_begin[kMaxSlabSegs + 1];
 };
 
 struct ProbsLaunch {        // daam_tap_probs

@@ -72,6 +72,9 @@ SLAB_CASES = [
     (8, 144, 80),        # 12 x 12 (768-px SD-v1.x): 4.5 tiles -- the last tile's second half lies outside the layer
     (8, 16, 40),         # 4 x 4: half a tile
     (4, 2304, 160),      # 48 x 48, two slabs
+    (8, 144, 40),        # hw % 32 == 16 with a tail: the main entries end / the tail entry begins on a 16-pixel (not a 32-pixel) boundary
+    (8, 400, 40),        # 20 x 20: the same, 12.5 tiles
+    (8, 25, 80),         # 5 x 5: a single, partial tile
 ]
 
 
@@ -111,9 +114,10 @@ def test_slab_sd15_launch_one_kernel_bit_identical_to_specialised_kernels(monkey
     assert rflush['kernels'] == 3, rflush
     got_eng = _engine(monkeypatch, True, len(shapes), 'exact', 64)
     got, flush, launch = _run(got_eng, shapes, sets)
+    names = got_eng.last_kernels(0)
     got_eng.close()
     assert flush['kernels'] == 1 and flush['side_streams'] == 0 and flush['max_steps'] == 50, flush
-    assert launch['block'] == 512, launch
+    assert launch['block'] == 512 and names == 'tap_slab_kernel', (launch, names)
     # segments: 168 head_dim-160 workgroups, 5 x 96 of head_dim 40 (32-pixel tiles: the first three quarters of each layer), 320 of head_dim
     # 80, 5 x 64 half-size ones (16-pixel tiles: the last quarter of the head_dim-40 layers); an eighth of each segment per XCD
     assert launch['grid'] == 8 * (21 + 60 + 40 + 40), launch
