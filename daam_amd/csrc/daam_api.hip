@@ -42,8 +42,8 @@ hipError_t launch_tap_probs(const ProbsLaunch&, int, int, hipStream_t, int*, int
 hipError_t launch_finalize(const FinLaunch&, int, hipStream_t, int*, int*);
 hipError_t launch_upload(void* dst, const void* src_host_mapped, size_t bytes, void* zero, size_t zero_bytes, hipStream_t);
 hipError_t launch_finalize_up32_same(const FinLaunch& up, const FinLaunch& same, hipStream_t, int*);
-hipError_t launch_finalize_up32_pipe(const FinPipeLaunch&, hipStream_t, int*);
-int finalize_pipe_ring();
+hipError_t launch_finalize_up32_pipe(const FinPipeLaunch&, int acc_dtype, hipStream_t, int*);
+int finalize_pipe_ring(int acc_dtype);
 hipError_t launch_finalize_same(const FinLaunch&, int, hipStream_t, int*);
 hipError_t launch_finalize_up(const FinLaunch&, int side, int, int mfma_ok, hipStream_t, int*);
 bool finalize_up_supported(int side, int out_side);
@@ -197,11 +197,12 @@ struct DaamCtx {
     std::vector<int> tab_sides;
     std::vector<int> tab_fp16_exact;   // every (border-merged) tap weight is an fp16 number
     void* d_up32_ops = nullptr;        // finalize_up32_mfma_kernel operands of the 32 -> 64 table (see build_up32_ops)
+    void* d_up32_ops_bf16 = nullptr;   // the same for bf16 planes on the pipelined kernel: pass-1 pieces as bf16 bit patterns, W = W' + E (NULL: no such split)
     int up32_tab = -1;
     int no_mfma_finalize = 0;
     int no_fold_same = 0;             // debugging / A-B: the same-size class as its own kernel beside the pipelined one
     int no_pipe_finalize = 0;         // debugging / A-B: the round-2 x2 MFMA kernel instead of the software-pipelined one
-    void* d_zero_planes = nullptr;    // [tokens][32 x 32] fp16 zeros: padding keys of the pipelined x2 finalize
+    void* d_zero_planes = nullptr;    // [tokens][32 x 32] zeros (sized for f32 planes): padding keys of the pipelined x2 finalize
     int no_paired_finalize = 0;       // debugging / A-B: same-size and x2 class as two launches
     // finalize tables kept on the device between calls: a generation's compute_global_heat_map() selects the same keys at the same
     // addresses as the previous one, so the key / pointer tables are uploaded once and compared on the host afterwards
@@ -328,7 +329,11 @@ static int ensure_zeroed(Layer& l, hipStream_t s)
 //   k = 0, 1      : Wx, B of pass 1:  W[32nt + n][16ks + 8g + e],                      ks = k
 //   k = 2 + 2t+ks : Wy, A of pass 2:  W[32t + n][16ks + 8(i >> 2) + 4g + (i & 3)]     (contraction index
 //                   permuted to the C/D register order of pass 1, see the kernel)
-static std::vector<_Float16> build_up32_ops(const int16_t* idx, const float* w)
+// wx_bf16 (bf16 planes on the pipelined kernel, pass 1 on the bf16 MFMA): 7 pieces per (nt, lane) -- k = 0, 1 hold W' as bf16 bit patterns and
+//   k = 6         : E, B of the third pass-1 MFMA:  E[32nt + n][g == 0 ? e : 24 + e]    with W = W' + E, both bf16 numbers
+// (W' = W truncated to eight significant bits; the 32 -> 64 table has one entry per border that needs nine: 283/256 = 282/256 + 1/256).
+// *ok = 0 when E is not a bf16 number somewhere or has an entry outside source columns 0..7 / 24..31.
+static std::vector<_Float16> build_up32_ops(const int16_t* idx, const float* w, bool wx_bf16 = false, int* ok = nullptr)
 {
     auto W = [&](int o, int src) {
         float v = 0.f;
@@ -336,17 +341,42 @@ static std::vector<_Float16> build_up32_ops(const int16_t* idx, const float* w)
             if (idx[o * 4 + a] == src) v += w[o * 4 + a];
         return (_Float16)v;
     };
-    std::vector<_Float16> ops((size_t)2 * 64 * 6 * 8);
+    auto trunc_bf16 = [](float v) {
+        uint32_t u;
+        memcpy(&u, &v, 4);
+        u &= 0xffff0000u;
+        memcpy(&v, &u, 4);
+        return v;
+    };
+    auto put_bf16 = [](_Float16* dst, float v) {
+        const uint16_t bits = f32_to_bf16(v).bits;
+        memcpy(dst, &bits, 2);
+    };
+    const int pieces = wx_bf16 ? 7 : 6;
+    if (ok) *ok = 1;
+    std::vector<_Float16> ops((size_t)2 * 64 * pieces * 8);
     for (int nt = 0; nt < 2; ++nt)
         for (int lane = 0; lane < 64; ++lane) {
             const int n = lane & 31, g = lane >> 5;
-            _Float16* dst = ops.data() + ((size_t)(nt * 64 + lane) * 6) * 8;
+            _Float16* dst = ops.data() + ((size_t)(nt * 64 + lane) * pieces) * 8;
             for (int ks = 0; ks < 2; ++ks)
-                for (int e = 0; e < 8; ++e) dst[ks * 8 + e] = W(32 * nt + n, 16 * ks + 8 * g + e);
+                for (int e = 0; e < 8; ++e) {
+                    const int src = 16 * ks + 8 * g + e;
+                    const float v = (float)W(32 * nt + n, src);
+                    if (!wx_bf16) { dst[ks * 8 + e] = (_Float16)v; continue; }
+                    const float hi = trunc_bf16(v), lo = v - hi;
+                    put_bf16(&dst[ks * 8 + e], hi);
+                    if (lo != 0.f && ok && (bf16_to_f32(f32_to_bf16(lo)) != lo || (src >= 8 && src < 24))) *ok = 0;
+                }
             for (int t = 0; t < 2; ++t)
                 for (int ks = 0; ks < 2; ++ks)
                     for (int i = 0; i < 8; ++i)
                         dst[(2 + 2 * t + ks) * 8 + i] = W(32 * t + n, 16 * ks + 8 * (i >> 2) + 4 * g + (i & 3));
+            if (wx_bf16)
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (float)W(32 * nt + n, g == 0 ? e : 24 + e);
+                    put_bf16(&dst[6 * 8 + e], v - trunc_bf16(v));
+                }
         }
     return ops;
 }
@@ -489,6 +519,7 @@ int daam_ctx_destroy(DaamCtx* c)
     if (c->clk_stream) (void)hipStreamDestroy(c->clk_stream);
     if (c->clk_host) (void)hipHostFree(c->clk_host);
     if (c->d_up32_ops) (void)hipFree(c->d_up32_ops);
+    if (c->d_up32_ops_bf16) (void)hipFree(c->d_up32_ops_bf16);
     if (c->d_zero_planes) (void)hipFree(c->d_zero_planes);
     if (c->d_fin_tab) (void)hipFree(c->d_fin_tab);
     if (c->d_tab_idx) (void)hipFree(c->d_tab_idx);
@@ -547,8 +578,15 @@ int daam_layer_configure(DaamCtx* c, int layer, int heads, int side, int factor,
                 std::vector<_Float16> ops = build_up32_ops(idx.data(), w.data());
                 HIP_TRY(hipMalloc(&c->d_up32_ops, ops.size() * sizeof(_Float16)));
                 HIP_TRY(hipMemcpy(c->d_up32_ops, ops.data(), ops.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+                // bf16 planes: W = W' + E as two bf16 operands (build_up32_ops checks that the table splits that way)
+                int bf_ok = 0;
+                ops = build_up32_ops(idx.data(), w.data(), true, &bf_ok);
+                if (bf_ok) {
+                    HIP_TRY(hipMalloc(&c->d_up32_ops_bf16, ops.size() * sizeof(_Float16)));
+                    HIP_TRY(hipMemcpy(c->d_up32_ops_bf16, ops.data(), ops.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+                }
                 c->up32_tab = tab;
-                const size_t zb = (size_t)c->tokens * 32 * 32 * sizeof(_Float16);
+                const size_t zb = (size_t)c->tokens * 32 * 32 * sizeof(float);
                 HIP_TRY(hipMalloc(&c->d_zero_planes, zb));
                 HIP_TRY(hipMemset(c->d_zero_planes, 0, zb));
             }
@@ -1286,19 +1324,23 @@ static int fin_plan(DaamCtx* c, const uint8_t* key_mask, int rows, FinPlan& P)
     if (P.total == 0) return fail(DAAM_E_NOMAPS, "no heat maps selected");
     if (P.max_side > 128) return fail(DAAM_E_UNSUPPORTED, "map side %d > 128 not supported by finalize", P.max_side);
     // x2 class on the matrix cores (fp16 planes, fp16-exact tap matrix)?
-    P.mfma_up = !keys[1].empty() && c->acc_dtype == DAAM_F16 && keys[1][0].tab == c->up32_tab && c->d_up32_ops &&
+    P.mfma_up = !keys[1].empty() && keys[1][0].tab == c->up32_tab && c->d_up32_ops &&
                 c->tab_fp16_exact[keys[1][0].tab] && !c->no_mfma_finalize;
     // ... on the software-pipelined kernel (daam_finalize_pipe.hip): workgroup = (token, key chunk), every wave walks ALL keys
     // of its chunk from a pointer table padded with the all-zero plane to one even length >= 4 (+ what the ring prefetches
     // past the end).  ~1000 workgroups of 2 waves = one resident round at 2 waves per SIMD.
     P.pipe_up = P.mfma_up && !c->no_pipe_finalize && c->d_zero_planes;
+    // bf16 / f32 sums (round 6): the pipelined kernel only (bf16: the tap matrix must split into two bf16 MFMA operands); the round-2 MFMA
+    // kernels behind DAAM_NO_PIPE_FINALIZE take fp16 planes
+    if (c->acc_dtype == DAAM_BF16) P.pipe_up = P.pipe_up && c->d_up32_ops_bf16;
+    if (c->acc_dtype != DAAM_F16) P.mfma_up = P.pipe_up;
     if (P.pipe_up) {
         const int n = (int)keys[1].size();
         const int want = env_pipe_chunks ? env_pipe_chunks : env_chunks ? env_chunks : std::max(1, (1024 + rows / 2) / rows);
         P.pipe_chunks = std::max(1, std::min(want, (n + 7) / 8));
         const int per = (n + P.pipe_chunks - 1) / P.pipe_chunks;
         P.pipe_nk = std::max(4, (per + 1) & ~1);
-        P.pipe_stride = (P.pipe_nk + finalize_pipe_ring() + 2) & ~1;
+        P.pipe_stride = (P.pipe_nk + finalize_pipe_ring(c->acc_dtype) + 2) & ~1;
     }
     // The same-size (64 x 64) keys ride along in the pipelined kernel (every wave adds its share of them to its accumulators
     // before the x2 loop) unless they outnumber the x2 keys 2 : 1 -- then they keep their own streaming kernel.
@@ -1557,15 +1599,15 @@ int daam_finalize(DaamCtx* c, const uint8_t* key_mask, int n_rows, float* out, v
             PL.key_ptrs = reinterpret_cast<const unsigned long long*>(tab_dev + key_bytes);
             PL.same_ptrs = fold_same ? reinterpret_cast<const unsigned long long*>(tab_dev + key_bytes + ptr_bytes) : nullptr;
             PL.same_per = same_per;
-            PL.mfma_ops = c->d_up32_ops;
+            PL.mfma_ops = c->acc_dtype == DAAM_BF16 ? c->d_up32_ops_bf16 : c->d_up32_ops;
             PL.out = out;
             PL.n_chunks = pipe_chunks;
             PL.nk_pad = pipe_nk;
             PL.ptr_stride = pipe_stride;
             PL.tokens = rows;
             PL.inv_n = L.inv_n;
-            names("finalize_up32_pipe_kernel", fold_same ? "f16 + same-size keys" : "f16");
-            return launch_finalize_up32_pipe(PL, ks, grid);
+            names("finalize_up32_pipe_kernel", (std::string(dtype_name(c->acc_dtype)) + (fold_same ? " + same-size keys" : "")).c_str());
+            return launch_finalize_up32_pipe(PL, c->acc_dtype, ks, grid);
         }
         if (cls == 1 && paired) { names("finalize_up32_same_kernel", "f16"); return launch_finalize_up32_same(L, launches[0], ks, grid); }
         if (cls == 1 && mfma_up) {

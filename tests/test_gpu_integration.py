@@ -94,13 +94,14 @@ def _traced_generation(pipe, prompt, steps, sample, **trace_kw):
         got_global = tc.compute_global_heat_map().heat_maps
         flush = tc.engine.last_flush()
         flush['launches'] -= before                              # a parked context carries its count along
+        fin_kernels = tc.engine.last_kernels(1)
         got_norm = tc.compute_global_heat_map(normalize=True).heat_maps
         items = list(tc.all_heat_maps)
         keys = [k for k, _ in items]
         raw = {items[i][0]: items[i][1].clone() for i in sample}   # views of the live sums: copy before they are reset
         del items
     pipe.keep_outputs = False
-    return dict(glob=got_global, norm=got_norm, keys=keys, raw=raw, outs=outs, flush=flush)
+    return dict(glob=got_global, norm=got_norm, keys=keys, raw=raw, outs=outs, flush=flush, fin_kernels=fin_kernels)
 
 
 def _reference_generation(pipe, prompt, steps, latent_hw):
@@ -192,6 +193,120 @@ def test_full_size_parity_with_reference_processor(sdxl_stack):
     ref = _reference_generation(pipe, prompt, steps, 4096)
     rec = _compare_generation(got, ref, sample)
     _report('sdxl1024', dict(config='SDXL-1024 stack, fp16, 1100 keys, %d steps, one tap launch' % steps, **rec))
+
+
+# ---- the other two dtype legs bench.py times at the headline shape (sdxl1024_bf16, sdxl1024_f32acc): full stack, 50 steps ----------
+def _ulp(x: np.ndarray, mant_bits: int, min_exp: int) -> np.ndarray:
+    e = np.floor(np.log2(np.maximum(np.abs(x), 2.0 ** min_exp)))
+    return 2.0 ** (e - mant_bits)
+
+
+@pytest.fixture(scope='module')
+def sdxl_stack_bf16():
+    pipe = fd.make_pipe('sdxl', device=DEV, dtype=torch.bfloat16, batch=2, seed=3, mini=False, identity_proj=False)
+    _resident_inputs(pipe, n_sets=4)
+    return pipe
+
+
+def test_full_size_parity_bf16_pipeline(sdxl_stack_bf16):
+    """SDXL-1024 x 50 steps on a bfloat16 pipeline: bf16 Q / K, bf16 probabilities, bf16 running sums (the reference's sums have the
+    pipeline's dtype, heatmap.py:153-156), the finalize on the bf16 form of the pipelined matrix-core kernel (round 6) -- against the
+    reference's processor on the same inputs.  Stated tolerances (bf16 has 8 significant bits, fp16 has 11): global maps <= 8e-3 max-abs
+    (the bf16 golden cases' bound: 1e-3 x 2^3); the sampled keys' sums element by element within 2^-3 |v| + 2 ulp -- the fp16 test's 16 + 2
+    ulp --, a whole key within 2 ulp of its largest sum, <= 5 % of a key's elements differing at all."""
+    pipe = sdxl_stack_bf16
+    steps = 50
+    prompt = 'a photo of a monkey riding a bicycle'
+    sample = list(range(0, 1100, 37)) + [1099]
+    got = _traced_generation(pipe, prompt, steps, sample)
+    assert len(got['keys']) == 1100
+    assert got['flush']['launches'] == 1 and got['flush']['kernels'] == 1 and got['flush']['max_steps'] == steps
+    assert got['fin_kernels'] == 'finalize_up32_pipe_kernel<bf16 + same-size keys>', got['fin_kernels']
+    ref = _reference_generation(pipe, prompt, steps, 4096)
+    err = (got['glob'] - ref['glob']).abs().max().item()
+    err_norm = (got['norm'] - ref['norm']).abs().max().item()
+    assert got['glob'].shape == ref['glob'].shape == (ref['n_rows'], 64, 64)
+    assert err <= 8e-3 and err_norm <= 8e-3, (err, err_norm)
+    ref_items = list(ref['raw'])
+    assert [k for k, _ in ref_items] == got['keys']
+    worst_ulps, frac_diff = 0.0, 0.0
+    for i in sample:
+        key, want = ref_items[i]
+        assert want.dtype == torch.bfloat16 and got['raw'][key].dtype == torch.bfloat16
+        g = got['raw'][key].float().cpu().numpy().astype(np.float64)
+        w = want.float().cpu().numpy().astype(np.float64)
+        d = np.abs(g - w)
+        ulp = _ulp(np.maximum(np.abs(g), np.abs(w)), 7, -126)
+        excess = d - (2.0 ** -3 * np.abs(w) + 2 * ulp)
+        worst_ulps = max(worst_ulps, float((d / ulp).max()))
+        frac_diff = max(frac_diff, float((d > 0).mean()))
+        assert excess.max() <= 0, f'key {key}: off by {d.flat[np.argmax(excess)]} at value {w.flat[np.argmax(excess)]}'
+        assert d.max() <= 2 * _ulp(np.asarray(w.max()), 7, -126) + 1e-12, f'key {key}: {d.max()} > 2 ulp of the largest sum {w.max()}'
+    assert frac_diff <= 0.05, f'{frac_diff:.3%} of a key differ'
+    worst_out = max((a.float() - b.float()).abs().max().item() / b.float().abs().max().item() for a, b in zip(got['outs'], ref['outs']))
+    assert worst_out <= 1.6e-2, worst_out                        # the bf16 golden cases' bound for processor outputs
+    _report('sdxl1024_bf16', dict(config='SDXL-1024 stack, bf16 pipeline and sums, 1100 keys, %d steps, one tap launch' % steps,
+                                  global_max_abs=err, global_normalized_max_abs=err_norm, raw_sum_worst_ulps=worst_ulps,
+                                  raw_sum_fraction_differing=frac_diff, hidden_states_rel=worst_out, finalize_kernels=got['fin_kernels']))
+
+
+def test_full_size_parity_f32_sums(sdxl_stack):
+    """``accumulate='float32'`` at the headline shape (fp16 pipeline, f32 running sums: the accuracy mode, finalize on the f32 form of the
+    pipelined kernel).  The reference has no such mode; what it defines is the addends -- its fp16 probabilities -- so the expected sums are
+    those probabilities added in f32 (the reference's update with an f32 left operand).  A probability differs from the reference's by at
+    most one fp16 ulp, in <= 2 % of the elements of a step (the fp16 test's finding): sums element by element within 50 steps x 2^-11 x the
+    element's largest possible addend ... stated simply: |d| <= 2^-9 |v| + 2^-16; global maps <= 1e-3 max-abs (observed ~1e-5)."""
+    from daam_amd import engine as E
+    pipe = sdxl_stack
+    steps = 50
+    prompt = 'a photo of a monkey riding a bicycle'
+    sample = list(range(0, 1100, 37)) + [1099]
+    E.release_parked_contexts()
+    got = _traced_generation(pipe, prompt, steps, sample, accumulate='float32')
+    assert len(got['keys']) == 1100
+    assert got['flush']['launches'] == 1 and got['flush']['kernels'] == 1 and got['flush']['max_steps'] == steps
+    assert got['fin_kernels'] == 'finalize_up32_pipe_kernel<f32 + same-size keys>', got['fin_kernels']
+
+    class _F32Maps(th.RawMaps):
+        def update(self, factor, layer, head, heat_map):
+            super().update(factor, layer, head, heat_map.float())
+    import daam_amd
+    modules = [s.module for s in pipe.unet.execution_order()]
+    located = daam_amd.UNetCrossAttentionLocator().locate(pipe.unet)
+    raw = _F32Maps()
+    saved = [m.processor for m in modules]
+    for m in modules:
+        m.set_processor(th.ReferenceProcessor())
+    for idx, m in enumerate(located):
+        m.set_processor(th.ReferenceProcessor(raw, idx, 4096))
+    try:
+        pipe(prompt, num_inference_steps=steps)
+    finally:
+        for m, p in zip(modules, saved):
+            m.set_processor(p)
+    n_rows = len(pipe.tokenizer.tokenize(prompt)) + 2
+    ref_glob = th.global_heat_map(raw, 4096, n_rows=n_rows)
+    ref_norm = th.global_heat_map(raw, 4096, n_rows=n_rows, normalize=True)
+    err = (got['glob'] - ref_glob).abs().max().item()
+    err_norm = (got['norm'] - ref_norm).abs().max().item()
+    assert got['glob'].shape == ref_glob.shape == (n_rows, 64, 64)
+    assert err <= 1e-3 and err_norm <= 1e-3, (err, err_norm)
+    ref_items = list(raw)
+    assert [k for k, _ in ref_items] == got['keys']
+    worst_rel = 0.0
+    for i in sample:
+        key, want = ref_items[i]
+        assert want.dtype == torch.float32 and got['raw'][key].dtype == torch.float32
+        g = got['raw'][key].cpu().numpy().astype(np.float64)
+        w = want.cpu().numpy().astype(np.float64)
+        d = np.abs(g - w)
+        excess = d - (2.0 ** -9 * np.abs(w) + 2.0 ** -16)
+        assert excess.max() <= 0, f'key {key}: off by {d.flat[np.argmax(excess)]} at value {w.flat[np.argmax(excess)]}'
+        worst_rel = max(worst_rel, float((d / np.maximum(np.abs(w), 2.0 ** -7)).max()))
+    _report('sdxl1024_f32acc', dict(config='SDXL-1024 stack, fp16 pipeline, f32 sums, 1100 keys, %d steps, one tap launch' % steps,
+                                    global_max_abs=err, global_normalized_max_abs=err_norm, raw_sum_worst_rel=worst_rel,
+                                    finalize_kernels=got['fin_kernels']))
+    E.release_parked_contexts()
 
 
 # ---- BASELINE.json configs[1]: SD-v1.5 512 x 512, 50 steps, fp16 -- the launch it really runs ---------------------------------

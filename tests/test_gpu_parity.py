@@ -13,12 +13,13 @@ MI355X.  Tolerances are stated next to each comparison:
 """
 import json
 import math
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, golden_pipe, load_golden
+from conftest import GOLDEN_CASES, ROOT, golden_pipe, load_golden
 from oracle import heatmap_oracle as ho
 from oracle.make_golden import OUT_SAMPLE_ROWS, SAMPLE_TOKENS
 
@@ -273,36 +274,50 @@ def test_finalize_many_x2_keys(n_keys, path, monkeypatch):
 
 @pytest.mark.parametrize('fold', ['fold', 'nofold'])
 @pytest.mark.parametrize('n_keys', [1, 2, 3, 5, 8, 13, 27, 104, 105, 1000, 1001])
-def test_finalize_pipe_key_counts(n_keys, fold, monkeypatch):
+@pytest.mark.parametrize('acc', ['float16', 'bfloat16', 'float32'])
+def test_finalize_pipe_key_counts(n_keys, fold, acc, monkeypatch):
     """The software-pipelined x2 kernel walks a pointer table padded with all-zero planes to an even length >= 4 per chunk:
     key counts around every padding / chunking boundary (1 key = 3 padding planes; 13 chunks from 104 keys on; odd shares),
     with a same-size layer (two or five 64 x 64 keys) whose keys ride along in the same kernel (``fold``) or run as their own
-    kernel on a second stream (``nofold``).  Key i = plane set (i mod 27) scaled by 2^-(i mod 3)."""
+    kernel on a second stream (``nofold``).  Key i = plane set (i mod 27) scaled by 2^-(i mod 3).  ``acc`` = dtype of the sums:
+    fp16, bf16 (pass 1 on the bf16 MFMA, the tap matrix as two bf16 operands) and f32 (4 KiB planes split into an fp16 hi + lo pair in the
+    kernel; folded same-size keys on the VALU) each have their own generated schedule (round 6)."""
     monkeypatch.setenv('DAAM_NO_MFMA_FINALIZE', '0')
     monkeypatch.setenv('DAAM_NO_PIPE_FINALIZE', '0')
     monkeypatch.setenv('DAAM_NO_FOLD_SAME', '1' if fold == 'nofold' else '0')   # same-size keys inside the pipelined kernel / beside it
     rng = np.random.default_rng(1000 + n_keys)
     base_n, side = 27, 32
-    base = (rng.standard_normal((base_n, side * side, 77)) * 3).astype(np.float16)
+    np_dt = ho.BF16 if acc == 'bfloat16' else acc
+    t_dt = getattr(torch, acc)
+
+    def planes_of(shape):
+        x = rng.standard_normal(shape).astype(np.float32) * 3
+        return ho.round_bf16(x) if acc == 'bfloat16' else x.astype(acc)
+    base = planes_of((base_n, side * side, 77))
     per_key = np.stack([ho.global_heat_map([((2, 0, 0), ho.unravel(np.concatenate([base[i:i + 1]] * 2))[0])], 4096)
                         for i in range(base_n)]).astype(np.float64)
     scales = 2.0 ** -(np.arange(n_keys) % 3)
     n_same = 5 if n_keys >= 8 else 2                                                        # layer 1: 64 x 64 keys
-    same = (rng.standard_normal((2 * n_same, 64 * 64, 77)) * 3).astype(np.float16)
+    same = planes_of((2 * n_same, 64 * 64, 77))
     same_maps = [ho.global_heat_map([((1, 1, h), ho.unravel(same)[h])], 4096).astype(np.float64) for h in range(n_same)]
     want = sum(same_maps)
     for i in range(n_keys):
         want = want + scales[i] * per_key[i % base_n]
     want /= n_keys + n_same
-    eng = _engine(n_layers=2, accumulate='exact')
-    bd = torch.from_numpy(base).to(DEV)
+    eng = _engine(n_layers=2, accumulate='float32' if acc == 'float32' else 'exact')
+    bd = _dev(base, np_dt)
     idx = torch.arange(n_keys, device=DEV)
-    planes = bd[idx % base_n] * torch.from_numpy(scales.astype(np.float16)).to(DEV)[:, None, None]
+    planes = bd[idx % base_n] * torch.from_numpy(scales.astype(np.float32)).to(DEV).to(t_dt)[:, None, None]   # exact: powers of two
     eng.tap_probs(0, torch.cat([torch.zeros_like(planes), planes]), factor=2)
-    eng.tap_probs(1, torch.from_numpy(same).to(DEV), factor=1)
+    eng.tap_probs(1, _dev(same, np_dt), factor=1)
     for _ in range(2):                                                                     # twice: the table ring advances
         got = eng.global_heat_map().cpu().numpy()
         assert np.abs(got - want).max() <= 3e-6 * max(1.0, np.abs(want).max()), n_keys
+    names = eng.last_kernels(1)
+    tag = {'float16': 'f16', 'bfloat16': 'bf16', 'float32': 'f32'}[acc]
+    folded = fold == 'fold'
+    assert f'finalize_up32_pipe_kernel<{tag}' + (' + same-size keys>' if folded else '>') in names, names
+    assert ('finalize_same_kernel' in names) == (not folded), names
     only = eng.global_heat_map(factors=[2]).cpu().numpy()                                  # the x2 class alone (no second stream)
     want2 = sum(scales[i] * per_key[i % base_n] for i in range(n_keys)) / n_keys
     assert np.abs(only - want2).max() <= 3e-6 * max(1.0, np.abs(want2).max())
@@ -671,8 +686,13 @@ def test_trace_api_matches_reference_golden(golden_case, tap, defer, tmp_path):
         np.testing.assert_allclose(whm.expand_as(_Img()).numpy(), z['word_expand_128'], rtol=0,
                                    atol=max(2e-5, 4 * _global_tol(meta) / max(span, 1e-6)) if meta['dtype'] != 'float32'
                                    else 5e-5)
-        np.testing.assert_allclose(whm.expand_as(_Img(), absolute=True).numpy(), z['word_expand_128_abs'], rtol=0,
-                                   atol=max(2e-5, _global_tol(meta)))
+        got_abs = whm.expand_as(_Img(), absolute=True).numpy()
+        if not np.allclose(got_abs, z['word_expand_128_abs'], rtol=0, atol=max(2e-5, _global_tol(meta))):
+            # seen ONCE (round 6, four test processes on one GPU): 64 consecutive elements off.  Keep what is needed to tell a lost write from a late one.
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            np.savez(os.path.join(ROOT, 'gpurun_out', f'expand_mismatch_{name}_{os.getpid()}.npz'), got=got_abs, again=whm.expand_as(_Img(), absolute=True).numpy(),
+                     want=z['word_expand_128_abs'], norm=z['word_expand_128'], word=whm.heatmap.cpu().numpy())
+        np.testing.assert_allclose(got_abs, z['word_expand_128_abs'], rtol=0, atol=max(2e-5, _global_tol(meta)))
         assert tc.layer_names == json.loads(str(z['layer_names']))
         assert tc.last_prompt == str(z['last_prompt'])
         assert str(tc.last_image) == str(z['last_image'])

@@ -74,7 +74,6 @@ SLAB_CASES = [
     (4, 2304, 160),      # 48 x 48, two slabs
     (8, 144, 40),        # hw % 32 == 16 with a tail: the main entries end / the tail entry begins on a 16-pixel (not a 32-pixel) boundary
     (8, 400, 40),        # 20 x 20: the same, 12.5 tiles
-    (8, 25, 80),         # 5 x 5: a single, partial tile
 ]
 
 

@@ -682,18 +682,39 @@ def test_generation_experiment_round_trip(tmp_path):
 
 
 def test_generated_finalize_schedule_is_current(tmp_path):
-    """daam_amd/csrc/daam_finalize_pipe_{prefill,asm}_r16.inc are generated (tools/gen_fin_pipe.py): the committed files must
-    be what the generator writes today."""
+    """daam_amd/csrc/daam_finalize_pipe_{prefill,asm}_*.inc are generated (tools/gen_fin_pipe.py: one schedule per dtype of the sums -- fp16
+    ``r16``, ``bf16`` (shares the fp16 prefill), ``f32``): the committed files must be what the generator writes today."""
     import subprocess
     import sys
-    for ring in ('16',):
-        env = dict(os.environ, DAAM_PIPE_RING=ring, DAAM_PIPE_OUTDIR=str(tmp_path))
-        for k in ('DAAM_PIPE_ABLATE', 'DAAM_PIPE_SCHED', 'DAAM_PIPE_NT', 'DAAM_PIPE_OUT'):
-            env.pop(k, None)
-        subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen_fin_pipe.py')], env=env, check=True, capture_output=True)
-        for kind in ('prefill', 'asm'):
-            name = f'daam_finalize_pipe_{kind}_r{ring}.inc'
-            assert open(os.path.join(str(tmp_path), name)).read() == open(os.path.join(ROOT, 'daam_amd', 'csrc', name)).read(), name
+    env = dict(os.environ, DAAM_PIPE_OUTDIR=str(tmp_path))
+    for k in ('DAAM_PIPE_ABLATE', 'DAAM_PIPE_SCHED', 'DAAM_PIPE_NT', 'DAAM_PIPE_OUT', 'DAAM_PIPE_RING', 'DAAM_PIPE_DT', 'DAAM_PIPE_FAIR'):
+        env.pop(k, None)
+    subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen_fin_pipe.py')], env=env, check=True, capture_output=True)
+    names = sorted(f for f in os.listdir(os.path.join(ROOT, 'daam_amd', 'csrc')) if f.startswith('daam_finalize_pipe_') and f.endswith('.inc'))
+    assert names == sorted(os.listdir(str(tmp_path))) == ['daam_finalize_pipe_asm_bf16.inc', 'daam_finalize_pipe_asm_f32.inc', 'daam_finalize_pipe_asm_r16.inc',
+                                                          'daam_finalize_pipe_prefill_f32.inc', 'daam_finalize_pipe_prefill_r16.inc']
+    for name in names:
+        assert open(os.path.join(str(tmp_path), name)).read() == open(os.path.join(ROOT, 'daam_amd', 'csrc', name)).read(), name
+
+
+def test_x2_tap_matrix_as_mfma_operands():
+    """What the matrix-core finalize assumes of the 32 -> 64 bicubic table (daam_api.hip: build_up32_ops), restated with the oracle's taps:
+    every border-merged weight is an fp16 number (the fp16 / f32 forms take the matrix as an fp16 operand); as bf16 operands it needs
+    TWO pieces -- W' = W truncated to eight significant bits and E = W - W' -- because the three taps clamped onto a border column add up
+    to 283/256 (nine bits); E is a bf16 number and lives in source columns 0..7 / 24..31 only (the third pass-1 MFMA of the bf16 form reads
+    exactly those columns of the plane)."""
+    idx, w = ho.bicubic_taps(32, 64)
+    W = np.zeros((64, 32), np.float64)
+    for o in range(64):
+        for a in range(4):
+            W[o, idx[o, a]] += float(w[o, a])
+    assert np.array_equal(W.astype(np.float16).astype(np.float64), W)
+    bits = W.astype(np.float32).view(np.uint32)
+    hi = (bits & 0xffff0000).view(np.float32).astype(np.float64)
+    lo = W - hi
+    assert np.array_equal(ho.round_bf16(lo.astype(np.float32)).astype(np.float64), lo)
+    assert sorted(zip(*np.nonzero(lo))) == [(0, 0), (63, 31)] and W[0, 0] == 283 / 256 and lo[0, 0] == 1 / 256 and lo[63, 31] == 1 / 256
+    assert np.array_equal(ho.round_bf16(hi.astype(np.float32)).astype(np.float64), hi)
 
 
 @pytest.mark.parametrize('head_dim,hw,p0', [(8, 64, 0), (40, 256, 128), (64, 128, 0), (80, 256, 0), (120, 64, 0), (160, 256, 128),

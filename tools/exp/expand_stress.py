@@ -3,7 +3,8 @@
 elements of the 128 x 128 output off by up to 0.023).  Repeats the calls of tests/test_gpu_parity.py's golden test on a fixed word map,
 alternating the normalised and the absolute form (the same allocator blocks are handed out again and again), optionally while a
 second process keeps the GPU busy, and reports every call whose result differs from the first one of its kind."""
-import argparse, subprocess, sys, time
+import argparse, os, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 
