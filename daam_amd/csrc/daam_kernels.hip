@@ -293,6 +293,12 @@ __device__ __forceinline__ void cubic_coeffs(float t, float w[4]) {
     w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
 }
 
+// Results the caller copies to the host right behind the kernel (expand_as returns a CPU tensor, heatmap.py:88) are stored write-through
+// (system scope): the copy engine reads memory, not the L2s.  Round 6 saw ONE expand_as result in ~10^5 whose 64 consecutive elements (two
+// cache lines) still held the block's previous owner's data after the copy (four test processes sharing the GPU; not reproduced in 80 000
+// calls) -- with write-through stores the result does not depend on when an L2 writes a dirty line back.
+__device__ __forceinline__ void store_for_host(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // one thread per output pixel; source plane (<= 96x96 f32) is L1/L2 resident
 __global__ __launch_bounds__(256) void word_expand_kernel(const float* word_map, int side, float* out, int out_h,
                                                           int out_w, float* minmax)
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(256) void word_expand_kernel(const float* word_map,
             }
             v = rows[0] * wy[0] + rows[1] * wy[1] + rows[2] * wy[2] + rows[3] * wy[3];
         }
-        out[i] = v;
+        store_for_host(out + i, v);
     }
     // wave64 min / max, one atomic pair per wave
     float lo = valid ? v : INFINITY, hi = valid ? v : -INFINITY;
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256) void word_post_kernel(float* out, int n, const
         v = (v - lo) / (hi - lo + 1e-8f);
     }
     if (threshold != 0.f) v = v > threshold ? 1.f : 0.f;      // `if threshold:` (heatmap.py:85)
-    out[i] = v;
+    store_for_host(out + i, v);
 }
 
 // ---------------------------------------------------------------------------------------
