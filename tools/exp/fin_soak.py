@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Round 6: soak of the three generated schedules of the pipelined finalize (fp16 / bf16 / f32 sums).  The kernel's ring protocol is counted
+waits + one barrier per plane in hand-written asm: a wrong count would show as a rare, timing-dependent wrong plane.  SDXL-1024 key set, the same
+finalize ``--calls`` times per dtype (full 77 rows and a 12-row call alternating), every result compared with the first one of its kind (the
+atomics' order moves the last bits: tolerance 4e-6 x max|map|), optionally with busy processes beside it.  Writes gpurun_out/fin_soak.json."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+
+import bench
+from daam_amd.engine import HeatMapEngine
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--calls', type=int, default=4000)
+    ap.add_argument('--noise', type=int, default=0)
+    ap.add_argument('--child', action='store_true')
+    a = ap.parse_args()
+    if a.child:
+        x = torch.randn(8192, 8192, device='cuda', dtype=torch.float16)
+        t0 = time.time()
+        while time.time() - t0 < 600:
+            y = x @ x
+            torch.cuda.synchronize()
+        return
+    kids = [subprocess.Popen([sys.executable, __file__, '--child']) for _ in range(a.noise)]
+    dev = torch.device('cuda', 0)
+    layers = bench.topology('sdxl', 128)
+    out = {}
+    try:
+        for name, dtype, accumulate in (('f16', torch.float16, 'exact'), ('bf16', torch.bfloat16, 'exact'), ('f32', torch.float16, 'float32')):
+            sets = bench.make_inputs(layers, 2, dev, 1, dtype=dtype)
+            eng = HeatMapEngine(len(layers), tokens=77, out_side=64, accumulate=accumulate, defer_steps=4)
+            for t in range(4):
+                for (layer, heads, side, d), (q, k) in zip(layers, sets[t % 2]):
+                    eng.tap_qk(layer, q, k, heads, d ** -0.5, 64 // side if side <= 64 else 0)
+            eng.flush()
+            ref = {r: eng.global_heat_map(n_rows=r).clone() for r in (77, 12)}
+            tol = {r: 4e-6 * float(ref[r].abs().max()) for r in ref}
+            worst, bad = 0.0, 0
+            t0 = time.time()
+            for i in range(a.calls):
+                r = 77 if i % 2 == 0 else 12
+                d = float((eng.global_heat_map(n_rows=r) - ref[r]).abs().max())
+                worst = max(worst, d / tol[r])
+                bad += d > tol[r]
+            out[name] = dict(calls=a.calls, differing=int(bad), worst_over_tolerance=round(worst, 4), seconds=round(time.time() - t0, 1),
+                             kernels=eng.last_kernels(1), noise=a.noise)
+            print(name, out[name], flush=True)
+            eng.close()
+            del sets
+    finally:
+        for k in kids:
+            k.kill()
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(out, open(f'gpurun_out/fin_soak_noise{a.noise}.json', 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
