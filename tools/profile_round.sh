@@ -5,7 +5,8 @@
 # usage: tools/profile_round.sh <tag> [workload [denoise steps [defer]]]     e.g.  tools/profile_round.sh r02 sdxl1024 50 50
 set -u
 TAG=${1:-r03}; WL=${2:-sdxl1024}; DS=${3:-50}; DEFER=${4:-$DS}; NSTAT=${5:-30}; NPMC=${6:-5}
-KEY=$WL:defer$DEFER:exact
+ACC=exact; [ "$WL" = sdxl1024_f32acc ] && ACC=float32
+KEY=$WL:defer$DEFER:$ACC
 R=$(pwd); O=$R/gpurun_out/prof_${TAG}_$WL
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 ARGS="--no-baselines --no-integrated --no-other-configs --no-pmc --no-sustained --workload $WL --denoise-steps $DS"
