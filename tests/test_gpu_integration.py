@@ -251,11 +251,12 @@ def test_full_size_parity_bf16_pipeline(sdxl_stack_bf16):
 
 
 def test_full_size_parity_f32_sums(sdxl_stack):
-    """``accumulate='float32'`` at the headline shape (fp16 pipeline, f32 running sums: the accuracy mode, finalize on the f32 form of the
-    pipelined kernel).  The reference has no such mode; what it defines is the addends -- its fp16 probabilities -- so the expected sums are
-    those probabilities added in f32 (the reference's update with an f32 left operand).  A probability differs from the reference's by at
-    most one fp16 ulp, in <= 2 % of the elements of a step (the fp16 test's finding): sums element by element within 50 steps x 2^-11 x the
-    element's largest possible addend ... stated simply: |d| <= 2^-9 |v| + 2^-16; global maps <= 1e-3 max-abs (observed ~1e-5)."""
+    """``accumulate='float32'`` at the headline shape (fp16 pipeline, f32 running sums: the accuracy mode; finalize on the f32 form of the
+    pipelined kernel).  The reference has no such mode; what it defines are the addends -- its fp16 probabilities (trace.py:276) -- so the
+    expected sums are those probabilities added in f32 (the reference's ``update``, heatmap.py:153-156, with an f32 left operand).  Stated
+    tolerances: a traced probability differs from the reference's by at most one fp16 ulp (2^-11 relative) in a few per cent of the steps at
+    most, so a 50-step sum is within ``2^-9 |v| + 2^-16`` element by element (observed: 1e-3 relative at worst); global maps <= 1e-3 max-abs
+    (observed 1.1e-5)."""
     from daam_amd import engine as E
     pipe = sdxl_stack
     steps = 50
