@@ -174,7 +174,8 @@ def iteration_f32(pi, do_c=True, do_d=True, do_b=True, do_a=True, do_dma=True):
     d = stage_D(1 - pi) if do_d else []
     b = stage_B(1 - pi) if do_b else []
     if do_c and do_a:
-        valu = d[:16] + b + (['LGKM'] if do_dma else ['WAIT']) + split_P_hi() + (['KEY'] if do_dma else []) + split_P_lo() + d[16:]
+        assert do_dma
+        valu = d[:16] + b + ['LGKM'] + split_P_hi() + ['KEY'] + split_P_lo() + d[16:]
         per = 8
     else:
         assert not do_a and not do_dma
@@ -189,8 +190,6 @@ def iteration_f32(pi, do_c=True, do_d=True, do_b=True, do_a=True, do_dma=True):
             k += 1
             if v == 'LGKM':
                 L += ['s_waitcnt lgkmcnt(0)'] + dma(S_BASE)
-            elif v == 'WAIT':
-                L += ['s_waitcnt lgkmcnt(0)']
             elif v == 'KEY':
                 L += next_key()
             else:
