@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Generates daam_amd/csrc/daam_finalize_pipe_prefill.inc and daam_finalize_pipe_asm.inc: the software-pipelined main loop of the
+"""Generates daam_amd/csrc/daam_finalize_pipe_{prefill,asm}_{r16,bf16,f32}.inc (one schedule per dtype of the running sums: fp16 planes = r16,
+bf16 planes -- which share the fp16 prefill --, f32 planes): the software-pipelined main loop of the
 x2 (32 -> 64) finalize on the matrix cores as hand-scheduled inline asm (fixed physical registers, counted waits, LDS-DMA plane
 ring): statement 1 starts the ring's first R planes, statement 2 is the pipeline (the kernel runs its same-size keys between the
 two, under the latency of the prefill).
@@ -29,8 +30,9 @@ import os
 
 import sys
 
-# Plane dtype of the generated variant (round 6): 'f16' (the original), 'bf16' (pass 1 on v_mfma_f32_32x32x16_bf16 -- plane and Wx are bf16
-# MFMA operands as they are, everything behind pass 1 is the f16 variant's), 'f32' (4 KiB planes: every lane reads its A pieces as 16
+# Plane dtype of the generated variant (round 6): 'f16' (the original, described above), 'bf16' (pass 1 on v_mfma_f32_32x32x16_bf16: the plane is
+# its A operand as it is, the tap matrix goes in as two bf16 matrices W' + E with a third MFMA for E -- see PMIX below; everything behind pass 1
+# is the f16 variant's), 'f32' (4 KiB planes: every lane reads its A pieces as 16
 # floats and splits them into an fp16 hi + lo pair like pass 2 splits T -- 32 more VALU instructions and 2 more MFMAs per plane; ring of
 # 8 planes = the same 32 KiB; two LDS-DMA instructions per plane and wave; the 16-byte pieces of a 128-byte plane row are XOR-swizzled
 # with (row >> 1) & 7 on the SOURCE address so that the ds_read_b128 of 32 rows x one piece column are conflict-free).
