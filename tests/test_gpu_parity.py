@@ -919,27 +919,34 @@ def test_tap_property(heads, side, d, batch, steps, defer, mode, seed):
     np.testing.assert_allclose(got.sum(1), steps, atol=steps * 77 * half_ulp)
 
 
-@settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
-@given(sides=st.lists(st.sampled_from([8, 16, 32, 64, 128]), min_size=1, max_size=4), acc=st.sampled_from(['float16', 'float32']),
-       heads=st.integers(1, 3), seed=st.integers(0, 2 ** 16))
-def test_finalize_property(sides, acc, heads, seed):
-    """Any mix of map sizes: mean over keys of clamp(bicubic(plane)) matches the oracle; linear in a
-    positive scale of the inputs (clamp and bicubic are positively homogeneous)."""
+@settings(max_examples=80, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(sides=st.lists(st.sampled_from([8, 16, 32, 32, 64, 128]), min_size=1, max_size=4), acc=st.sampled_from(['float16', 'float32', 'bfloat16']),
+       heads=st.integers(1, 9), n_rows=st.sampled_from([None, 1, 5, 12, 40, 77]), pick=st.sampled_from(['all', 'head', 'layer', 'factor']),
+       seed=st.integers(0, 2 ** 16))
+def test_finalize_property(sides, acc, heads, n_rows, pick, seed):
+    """Any mix of map sizes, any dtype of the sums (fp16 / bf16 / f32: each has its own form of the matrix-core x2 kernel), any row count
+    (ABI v6) and any of the reference's selections (trace.py:113): mean over keys of clamp(bicubic(plane)) matches the oracle; linear in a
+    positive power-of-two scale of the inputs (clamp and bicubic are positively homogeneous)."""
     rng = np.random.default_rng(seed)
-    eng = _engine(n_layers=len(sides), accumulate='exact' if acc == 'float16' else 'float32')
-    eng2 = _engine(n_layers=len(sides), accumulate='exact' if acc == 'float16' else 'float32')
+    accumulate = 'float32' if acc == 'float32' else 'exact'
+    np_dt = ho.BF16 if acc == 'bfloat16' else acc
+    eng = _engine(n_layers=len(sides), accumulate=accumulate)
+    eng2 = _engine(n_layers=len(sides), accumulate=accumulate)
     raw = []
     for layer, side in enumerate(sides):
-        planes = (rng.standard_normal((2 * heads, side * side, 77)) * 2).astype(acc)
+        planes = rng.standard_normal((2 * heads, side * side, 77)).astype(np.float32) * 2
+        planes = ho.round_bf16(planes) if acc == 'bfloat16' else planes.astype(acc)
         factor = 64 // side if side <= 64 else 0
-        eng.tap_probs(layer, torch.from_numpy(planes).to(DEV), factor=factor)
-        eng2.tap_probs(layer, torch.from_numpy((planes * np.asarray(2, dtype=acc))).to(DEV), factor=factor)
+        eng.tap_probs(layer, _dev(planes, np_dt), factor=factor)
+        eng2.tap_probs(layer, _dev(planes * 2, np_dt), factor=factor)
         raw += [((factor, layer, h), ho.unravel(planes)[h]) for h in range(heads)]
-    want = ho.global_heat_map(raw, 4096)
-    got = eng.global_heat_map().cpu().numpy()
-    got2 = eng2.global_heat_map().cpu().numpy()
+    kw = {'all': {}, 'head': dict(head_idx=heads - 1), 'layer': dict(layer_idx=len(sides) - 1), 'factor': dict(factors=[raw[0][0][0]])}[pick]
+    want = ho.global_heat_map(raw, 4096, **kw)[:n_rows]
+    got = eng.global_heat_map(n_rows=n_rows, **kw).cpu().numpy()
+    got2 = eng2.global_heat_map(n_rows=n_rows, **kw).cpu().numpy()
     eng.close()
     eng2.close()
+    assert got.shape == want.shape
     tol = 3e-6 * max(1.0, np.abs(want).max())
     np.testing.assert_allclose(got, want, rtol=0, atol=tol)
     np.testing.assert_allclose(got2, 2 * got, rtol=0, atol=4 * tol)
